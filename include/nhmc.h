@@ -1,0 +1,211 @@
+/* nhmc.h -- C ABI of the MI355X-native noise-space HMC hot path (libnhmc.so).
+ *
+ * Every entry point
+ *   - takes raw DEVICE pointers, sizes, per-chain scalar arrays and a hipStream_t
+ *     (passed as void*; NULL = the null stream);
+ *   - is asynchronous on that stream, allocates nothing, never synchronises;
+ *   - returns an int status (NHMC_OK = 0); no C++ exception crosses the boundary;
+ *   - may be called concurrently on different streams / devices.
+ *
+ * "Reference" below is Sunsett5/Noise-space-HMC; file:line are relative to its root.
+ * The reference has no FFI: its hot path is Python issuing ATen ops.  Each function
+ * names the reference lines whose arithmetic it replaces; INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Layout conventions
+ *   images   : fp32, [n_chains][C][H][W] contiguous (NCHW), n_elem = C*H*W per chain,
+ *              n_elem % 4 == 0 and base pointers 16-byte aligned (NHMC_ERR_ALIGN otherwise)
+ *   score    : fp32, [n_chains][e_channels][H][W], e_channels in {C, 2C}; only the first
+ *              C channels are read (learned-sigma channels ignored, algos/unconditional.py:17-18)
+ *   y        : fp32, [n_chains][M]
+ *   per-chain scalars : device arrays of length n_chains (double for the sampler's
+ *              Python-float quantities eps / sigma_y, float for alpha-bar)
+ *   partial-sum workspaces : double, sized by the matching *_ws_bytes(); reductions are
+ *              two-pass and deterministic (no float atomics)
+ */
+#ifndef NHMC_H
+#define NHMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nhmc_stream_t; /* hipStream_t */
+
+enum {
+  NHMC_OK = 0,
+  NHMC_ERR_ARG = 1,    /* null pointer / non-positive size / unknown mode */
+  NHMC_ERR_ALIGN = 2,  /* pointer not 16-byte aligned or n_elem % 4 != 0 */
+  NHMC_ERR_SHAPE = 3,  /* shape combination the kernel does not cover */
+  NHMC_ERR_LAUNCH = 4  /* hipGetLastError() after launch != hipSuccess */
+};
+
+#define NHMC_ABI_VERSION 1
+int nhmc_abi_version(void);
+const char* nhmc_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * a1-a4  Fused leapfrog update            main_sampling.py:702,706-707,713,715
+ *
+ *   G  = x + (1/(2 sigma_y^2)) * (g [+ g2])
+ *   NHMC_LF_FIRST : Sx,Sp partials of (x,p) BEFORE the update (for H at :697);
+ *                   p -= (eps/2) G ; x += (eps/m) p
+ *   NHMC_LF_MID   : p -= eps G     ; x += (eps/m) p          <- the north-star kernel, 5T/chain
+ *   NHMC_LF_LAST  : p -= eps G ; p += (eps/2) G ; x unchanged;
+ *                   Sx,Sp partials AFTER the update (for H at :717)
+ * fp32 op order and scalar rounding follow the reference (scalars are fp64 products
+ * rounded once to fp32).  g2 (nullable) is a second gradient contribution added to g
+ * before use (the U-Net input-gradient of the first DDIM step), saving a separate add pass.
+ * sums_ws: double[n_chains][nhmc_leapfrog_tiles(n_elem)][2]; written in FIRST/LAST, may be
+ * NULL in MID.
+ * ---------------------------------------------------------------------------------- */
+enum { NHMC_LF_FIRST = 0, NHMC_LF_MID = 1, NHMC_LF_LAST = 2 };
+int nhmc_leapfrog_tiles(int64_t n_elem);
+size_t nhmc_leapfrog_ws_bytes(int n_chains, int64_t n_elem);
+int nhmc_leapfrog_fused(int mode, float* x, float* p, const float* g, const float* g2,
+                        const double* eps, const double* sigma_y, double m_inv,
+                        int n_chains, int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a9-a10  DDIM mix, forward               algos/unconditional.py:17-28, main_sampling.py:709
+ *   u = (xt - e*sqrt(1-at)) / sqrt(at);  x0 = clip(u,-1,1);  add = sqrt(1-at_next)*e;
+ *   xt_next = sqrt(at_next)*x0 + add;    if final_clip: xt_next = clip(xt_next,-1,1)
+ * Any of xt_next / x0_t / add_up may be NULL (not written): the fused sampler writes only
+ * xt_next (3T), the plugin surface's cal_x0 writes x0_t and add_up.
+ * at / at_next: float[n_chains] (the reference's [n,1,1,1] alpha-bar tensors).
+ * ---------------------------------------------------------------------------------- */
+int nhmc_ddim_mix_fwd(const float* xt, const float* e, int e_channels,
+                      const float* at, const float* at_next, int final_clip,
+                      float* xt_next, float* x0_t, float* add_up,
+                      int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
+
+/* map_back alone: xt_next = sqrt(at_next)*x0_t + add_up      algos/unconditional.py:26-28 */
+int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const float* at_next,
+                       float* xt_next, int n_chains, int64_t n_elem, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a11  DDIM mix, backward (the VJP autograd builds at main_sampling.py:695,711)
+ *   gin = gout (+ gout2);  if final_clip: gin *= 1[-1 <= xt_next <= 1]
+ *   g_xt = ((gin*sqrt(at_next)) * 1[-1<=u<=1]) / sqrt(at)
+ *   g_e[:, :C] = sqrt(1-at_next)*gin + (-g_xt)*sqrt(1-at);   g_e[:, C:] = 0
+ * g_e has e_channels channels (what the score network's backward consumes).
+ * ---------------------------------------------------------------------------------- */
+int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* xt, const float* e,
+                      int e_channels, const float* at, const float* at_next, int final_clip,
+                      float* g_xt, float* g_e,
+                      int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a12-a14  Data term: loss_b = sum (y_b - H clip(xt_b))^2 and d loss / d xt
+ *                                          main_sampling.py:693-695,709-711
+ * All write g_xt = -2 H^T r (masked by 1[-1<=xt<=1] when apply_clip) densely (no memset
+ * needed) and per-tile fp64 partials of sum r^2 into loss_ws; finish with
+ * nhmc_sum_partials(loss_ws, tiles, n_chains, loss).
+ *
+ * inpaint (obs_functions/Hfuncs.py:119-154): slot[j], j in CHW order, is the index into y of
+ *   pixel-element j, or -1 if that element is masked out.
+ * sr (Hfuncs.py:180-234): ratio r in {2,4,8,16,32}, W % 4 == 0, y laid out [C][H/r][W/r].
+ * ---------------------------------------------------------------------------------- */
+int nhmc_data_tiles(int64_t n_elem);                 /* tiles written by nhmc_data_inpaint / nhmc_psnr */
+int nhmc_sr_tiles(int channels, int dim, int ratio); /* tiles written by nhmc_data_sr */
+size_t nhmc_data_ws_bytes(int n_chains, int64_t n_elem);
+int nhmc_data_inpaint(const float* xt, const float* y, const int32_t* slot, int apply_clip,
+                      float* g_xt, double* loss_ws,
+                      int n_chains, int64_t n_elem, int64_t m, nhmc_stream_t stream);
+int nhmc_data_sr(const float* xt, const float* y, int ratio, int apply_clip,
+                 float* g_xt, double* loss_ws,
+                 int n_chains, int channels, int dim, nhmc_stream_t stream);
+int nhmc_sum_partials(const double* ws, int tiles, int stride, int offset, int n_chains,
+                      double* out, nhmc_stream_t stream);
+
+/* Operator surface H / H^T / H^+ (Hfuncs.py:65-90) for the same two operators.
+ * inpaint: kept_chw[k] = CHW address of y entry k.  scale: 1/r^2 for H^T, 1 for H^+. */
+int nhmc_inpaint_H(const float* x, const int32_t* kept_chw, float* y,
+                   int n_chains, int64_t n_elem, int64_t m, nhmc_stream_t stream);
+int nhmc_inpaint_Ht(const float* y, const int32_t* slot, float* x,
+                    int n_chains, int64_t n_elem, int64_t m, nhmc_stream_t stream);
+int nhmc_sr_H(const float* x, float* y, int ratio, int n_chains, int channels, int dim,
+              nhmc_stream_t stream);
+int nhmc_sr_Ht(const float* y, float* x, int ratio, float scale, int n_chains, int channels,
+               int dim, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a15  Spectral (anisotropic-blur) operator   Hfuncs.py:448-523
+ *   out_c = Lo (D_c o (L^T X_c R)) Ro^T      (H: L,R = V1,V2, Lo,Ro = U1,U2; H^T swaps them)
+ * as a chain of fp32-MFMA GEMMs against the four shared d x d factor matrices; d % 64 == 0.
+ * "Multiply by M from the left" consumes M^T's memory and "from the right" M's memory (k-major
+ * tiles for the MFMA fragments), so the host keeps both orientations of the factors resident.
+ * nhmc_spectral_apply   : one sandwich; L, R as stored, LoT = Lo^T, RoT = Ro^T as stored.
+ *                         tmp: float[n_chains*C*d*d] scratch.
+ * nhmc_data_spectral    : r = y - H clip(xt); loss partials (nhmc_spectral_tiles per chain);
+ *                         g_xt = -2 H^T r (masked).  factors: packed [8][d][d] =
+ *                         U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T.  tmp: float[2*n_chains*C*d*d] scratch.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_spectral_apply(const float* x, const float* L, const float* R, const float* Dmap,
+                        const float* LoT, const float* RoT, float* out, float* tmp,
+                        int n_chains, int channels, int dim, nhmc_stream_t stream);
+int nhmc_spectral_tiles(int channels, int dim);
+int nhmc_data_spectral(const float* xt, const float* y, const float* factors, const float* Dmap,
+                       int apply_clip, float* g_xt, double* loss_ws, float* tmp,
+                       int n_chains, int channels, int dim, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a5  Hamiltonian                          main_sampling.py:697,717-718
+ *   H = (0.5*Sx + (1/(2 sigma_y^2))*loss) + (0.5*Sp)*m^-1, per chain, in the reference's fp32
+ *   op order on fp32-rounded sums; Sx,Sp summed (fixed order, fp64) from the leapfrog partials.
+ * terms (nullable): double[n_chains][3] = Sx, Sp, loss as summed.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_hamiltonian(const double* sums_ws, int tiles, const double* loss, const double* sigma_y,
+                     double m_inv, float* H_out, double* terms, int n_chains,
+                     nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a6  Metropolis test, per chain, on the device (no host sync)   main_sampling.py:718-720
+ *   dH = H1 - H0;  accept = active && (u < min(1, exp(-dH)))
+ * ---------------------------------------------------------------------------------- */
+int nhmc_metropolis(const float* H0, const float* H1, const float* u, const int32_t* active,
+                    int32_t* accept, float* dH, int n_chains, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a7  Accept/reject bookkeeping and schedules   main_sampling.py:683-689,721-749
+ * nhmc_schedule_begin: per chain, active = epoch < epochs+2*sampling; sigma_y(epoch) anneal;
+ *   at epoch == epochs: sigma_y = sigma_0 and (tau > 0.1 -> tau = 0.1, eps = 0.01).
+ *   Inactive chains get eps_eff = 0 (frozen), active ones eps_eff = eps.
+ * nhmc_accept_commit: accepted chains copy x_prop -> x and, when epoch >= epochs+sampling,
+ *   xt_prop -> samples[chain][epoch-(epochs+sampling)] (samples: [n_chains][sampling][n_elem]).
+ *   Uses the PRE-increment epoch (:724-727); call before nhmc_schedule_end.
+ * nhmc_schedule_end: accept -> epoch += 1, rejected = 0; reject -> rejected += 1 and, from the
+ *   second consecutive reject on, tau *= 0.95, eps *= 0.95.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_schedule_begin(const int32_t* epoch, double* tau, double* eps, double* sigma_y,
+                        double* eps_eff, int32_t* active, double sigma_0, int epochs, int sampling,
+                        int n_chains, nhmc_stream_t stream);
+int nhmc_accept_commit(const int32_t* accept, const int32_t* epoch, float* x, const float* x_prop,
+                       const float* xt_prop, float* samples, int epochs, int sampling,
+                       int n_chains, int64_t n_elem, nhmc_stream_t stream);
+int nhmc_schedule_end(const int32_t* accept, const int32_t* active, int32_t* epoch,
+                      int32_t* rejected, double* tau, double* eps, int32_t* n_accept,
+                      int32_t* n_reject, int n_chains, nhmc_stream_t stream);
+
+/* PSNR of clamp((xt+1)/2,0,1) against clamp((x_orig+1)/2,0,1)   main_sampling.py:738-739
+ * ws: double[n_chains][nhmc_data_tiles(n_elem)]. */
+int nhmc_psnr(const float* xt, const float* x_orig, float* psnr, double* ws,
+              int n_chains, int64_t n_elem, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * a1  Momentum / accept noise: Philox4x32-10 keyed by seed, counted by
+ *     (element quad, chain_id0 + chain, draw, tag) -- independent of how chains are sharded.
+ *     Replaces torch.randn_like (main_sampling.py:692) and torch.rand(1) (:720).
+ * ---------------------------------------------------------------------------------- */
+int nhmc_randn_philox(float* out, uint64_t seed, uint32_t chain_id0, uint32_t draw, float scale,
+                      int n_chains, int64_t n_elem, nhmc_stream_t stream);
+int nhmc_uniform_philox(float* out, uint64_t seed, uint32_t chain_id0, uint32_t draw,
+                        int n_chains, nhmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NHMC_H */

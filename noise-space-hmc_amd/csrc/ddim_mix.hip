@@ -1,0 +1,209 @@
+// DDIM alpha/beta mixing, forward and VJP (rows a8-a11 of SURVEY.md section 8).
+// Replaces algos/unconditional.py:17-28 and the autograd nodes it generates
+// (main_sampling.py:695,711).  Reads the score network's [B, 2C, H, W] output in place:
+// only channels [0, C) are touched, so the learned-sigma half never moves through HBM.
+//
+// HBM-bound: forward R xt, R e[:C], W xt_next = 3T; backward R gout, xt, e[:C], W g_xt, g_e = 5T + C zeros.
+// grid = (tiles, chains); the per-chain alpha-bars come from small device arrays and the square
+// roots are taken in fp32 exactly as the reference takes them on its [n,1,1,1] tensors.
+#include "nhmc_common.h"
+
+namespace {
+
+struct Coef { float c1, c2, c3, c4; };
+
+__device__ __forceinline__ Coef coef(const float* at, const float* at_next, int chain) {
+  const float a = at[chain], an = at_next[chain];
+  Coef c;
+  c.c1 = sqrtf(1.0f - a);    // (1 - at).sqrt()
+  c.c2 = sqrtf(a);           // at.sqrt()
+  c.c3 = sqrtf(an);          // at_next.sqrt()
+  c.c4 = sqrtf(1.0f - an);   // (1 - at_next).sqrt()
+  return c;
+}
+
+template <bool W_NEXT, bool W_X0, bool W_ADD>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_fwd(
+    const float4* __restrict__ xt, const float4* __restrict__ e, int64_t e_stride4,
+    const float* __restrict__ at, const float* __restrict__ at_next, int final_clip,
+    float4* __restrict__ xt_next, float4* __restrict__ x0_t, float4* __restrict__ add_up, int64_t n4) {
+  const int chain = blockIdx.y;
+  const Coef k = coef(at, at_next, chain);
+  const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+  float4 xv[NHMC_VEC_PER_THREAD], ev[NHMC_VEC_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q < n4) { xv[i] = xt[base + q]; ev[i] = e[ebase + q]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    float4 o_next, o_x0, o_add;
+    const float* xe = reinterpret_cast<const float*>(&xv[i]);
+    const float* ee = reinterpret_cast<const float*>(&ev[i]);
+    float* on = reinterpret_cast<float*>(&o_next);
+    float* o0 = reinterpret_cast<float*>(&o_x0);
+    float* oa = reinterpret_cast<float*>(&o_add);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float u = (xe[c] - ee[c] * k.c1) / k.c2;
+      const float x0 = nhmc_clip1(u);
+      const float add = k.c4 * ee[c];
+      float nx = k.c3 * x0 + add;
+      if (final_clip) nx = nhmc_clip1(nx);
+      on[c] = nx; o0[c] = x0; oa[c] = add;
+    }
+    if (W_NEXT) xt_next[base + q] = o_next;
+    if (W_X0) x0_t[base + q] = o_x0;
+    if (W_ADD) add_up[base + q] = o_add;
+  }
+}
+
+__global__ __launch_bounds__(NHMC_BLOCK) void k_map_back(
+    const float4* __restrict__ x0_t, const float4* __restrict__ add_up, const float* __restrict__ at_next,
+    float4* __restrict__ xt_next, int64_t n4) {
+  const int chain = blockIdx.y;
+  const float c3 = sqrtf(at_next[chain]);
+  const int64_t base = (int64_t)chain * n4;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    const float4 a = x0_t[base + q], b = add_up[base + q];
+    float4 o;
+    o.x = c3 * a.x + b.x; o.y = c3 * a.y + b.y; o.z = c3 * a.z + b.z; o.w = c3 * a.w + b.w;
+    xt_next[base + q] = o;
+  }
+}
+
+template <bool HAS_G2>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
+    const float4* __restrict__ gout, const float4* __restrict__ gout2, const float4* __restrict__ xt,
+    const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
+    const float* __restrict__ at_next, int final_clip, float4* __restrict__ g_xt, float4* __restrict__ g_e,
+    int64_t n4) {
+  const int chain = blockIdx.y;
+  const Coef k = coef(at, at_next, chain);
+  const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+  float4 gv[NHMC_VEC_PER_THREAD], xv[NHMC_VEC_PER_THREAD], ev[NHMC_VEC_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q < n4) {
+      gv[i] = gout[base + q]; xv[i] = xt[base + q]; ev[i] = e[ebase + q];
+      if (HAS_G2) {
+        const float4 h = gout2[base + q];
+        gv[i].x += h.x; gv[i].y += h.y; gv[i].z += h.z; gv[i].w += h.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    float4 ox, oe;
+    const float* ge = reinterpret_cast<const float*>(&gv[i]);
+    const float* xe = reinterpret_cast<const float*>(&xv[i]);
+    const float* ee = reinterpret_cast<const float*>(&ev[i]);
+    float* gx = reinterpret_cast<float*>(&ox);
+    float* gee = reinterpret_cast<float*>(&oe);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float u = (xe[c] - ee[c] * k.c1) / k.c2;
+      float gin = ge[c];
+      if (final_clip) gin = gin * nhmc_in1(k.c3 * nhmc_clip1(u) + k.c4 * ee[c]);
+      const float gu = ((gin * k.c3) * nhmc_in1(u)) / k.c2;
+      gx[c] = gu;
+      gee[c] = k.c4 * gin + (-gu) * k.c1;
+    }
+    g_xt[base + q] = ox;
+    g_e[ebase + q] = oe;
+  }
+  // learned-sigma channels of the score gradient are zero (the forward slices them away)
+  const int64_t extra = e_stride4 - n4;
+  if (extra > 0) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+      const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+      if (q < extra) g_e[ebase + n4 + q] = z;
+    }
+  }
+}
+
+bool bad_shape(int n_chains, int channels, int64_t hw, int e_channels) {
+  return n_chains <= 0 || n_chains > 65535 || channels <= 0 || hw <= 0 ||
+         (e_channels != channels && e_channels != 2 * channels);
+}
+
+}  // namespace
+
+extern "C" int nhmc_ddim_mix_fwd(const float* xt, const float* e, int e_channels, const float* at,
+                                 const float* at_next, int final_clip, float* xt_next, float* x0_t,
+                                 float* add_up, int n_chains, int channels, int64_t hw, nhmc_stream_t stream) {
+  if (!xt || !e || !at || !at_next || (!xt_next && !x0_t && !add_up)) return NHMC_ERR_ARG;
+  if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
+  const int64_t n_elem = (int64_t)channels * hw;
+  if ((n_elem & 3) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(xt_next) ||
+      !nhmc_aligned16(x0_t) || !nhmc_aligned16(add_up))
+    return NHMC_ERR_ALIGN;
+  const int64_t n4 = n_elem / 4, es4 = (int64_t)e_channels * hw / 4;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  hipStream_t st = nhmc_s(stream);
+#define NHMC_FWD(A, B, C)                                                                             \
+  hipLaunchKernelGGL((k_mix_fwd<A, B, C>), grid, block, 0, st, (const float4*)xt, (const float4*)e, es4, \
+                     at, at_next, final_clip, (float4*)xt_next, (float4*)x0_t, (float4*)add_up, n4)
+  const int sel = (xt_next ? 4 : 0) | (x0_t ? 2 : 0) | (add_up ? 1 : 0);
+  switch (sel) {
+    case 4: NHMC_FWD(true, false, false); break;
+    case 3: NHMC_FWD(false, true, true); break;
+    case 7: NHMC_FWD(true, true, true); break;
+    case 6: NHMC_FWD(true, true, false); break;
+    case 5: NHMC_FWD(true, false, true); break;
+    case 2: NHMC_FWD(false, true, false); break;
+    default: NHMC_FWD(false, false, true); break;
+  }
+#undef NHMC_FWD
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const float* at_next, float* xt_next,
+                                  int n_chains, int64_t n_elem, nhmc_stream_t stream) {
+  if (!x0_t || !add_up || !at_next || !xt_next || n_chains <= 0 || n_elem <= 0) return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || !nhmc_aligned16(x0_t) || !nhmc_aligned16(add_up) || !nhmc_aligned16(xt_next))
+    return NHMC_ERR_ALIGN;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  hipLaunchKernelGGL(k_map_back, grid, block, 0, nhmc_s(stream), (const float4*)x0_t, (const float4*)add_up,
+                     at_next, (float4*)xt_next, n_elem / 4);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* xt, const float* e,
+                                 int e_channels, const float* at, const float* at_next, int final_clip,
+                                 float* g_xt, float* g_e, int n_chains, int channels, int64_t hw,
+                                 nhmc_stream_t stream) {
+  if (!gout || !xt || !e || !at || !at_next || !g_xt || !g_e) return NHMC_ERR_ARG;
+  if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
+  const int64_t n_elem = (int64_t)channels * hw;
+  if ((n_elem & 3) || !nhmc_aligned16(gout) || !nhmc_aligned16(gout2) || !nhmc_aligned16(xt) ||
+      !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e))
+    return NHMC_ERR_ALIGN;
+  const int64_t n4 = n_elem / 4, es4 = (int64_t)e_channels * hw / 4;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  hipStream_t st = nhmc_s(stream);
+  if (gout2)
+    hipLaunchKernelGGL((k_mix_bwd<true>), grid, block, 0, st, (const float4*)gout, (const float4*)gout2,
+                       (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, (float4*)g_xt,
+                       (float4*)g_e, n4);
+  else
+    hipLaunchKernelGGL((k_mix_bwd<false>), grid, block, 0, st, (const float4*)gout, (const float4*)nullptr,
+                       (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, (float4*)g_xt,
+                       (float4*)g_e, n4);
+  return nhmc_launch_status();
+}

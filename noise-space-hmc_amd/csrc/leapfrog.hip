@@ -1,0 +1,124 @@
+// Fused leapfrog momentum + position update (rows a1-a4 of SURVEY.md section 8).
+// Replaces main_sampling.py:702 (first half step), :706-707 (position), :713 (momentum),
+// :715 (last half-step undo) and produces the per-chain sums the Hamiltonians at :697/:717 need.
+//
+// HBM-bound streaming kernel: MID reads x,p,g and writes x,p = 20 B/element (5T per chain).
+// grid = (tiles, chains); 256 threads; every thread owns 4 float4 per stream, strided by the
+// block so each wave-instruction touches 1 KiB contiguous.  Per-chain scalars are fp64 device
+// values rounded once to fp32, exactly as `python_float * tensor` does in the reference.
+// Compiled with -ffp-contract=off: mul/add stay separate, matching the reference's ATen op order.
+#include "nhmc_common.h"
+
+namespace {
+
+template <int MODE, bool HAS_G2>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
+    float4* __restrict__ x, float4* __restrict__ p, const float4* __restrict__ g,
+    const float4* __restrict__ g2, const double* __restrict__ eps, const double* __restrict__ sigma_y,
+    double m_inv, int64_t n4, double* __restrict__ sums_ws) {
+  const int chain = blockIdx.y;
+  const double e = eps[chain], s = sigma_y[chain];
+  const float kf = (float)(1.0 / (2.0 * (s * s)));   // 1/(2*sigma_y**2)
+  const float ef = (float)e;                          // epsilon
+  const float eh = (float)(e / 2.0);                  // epsilon / 2
+  const float ex = (float)(e * m_inv);                // epsilon * m**(-1)
+
+  const int64_t base = (int64_t)chain * n4;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+
+  float4 xv[NHMC_VEC_PER_THREAD], pv[NHMC_VEC_PER_THREAD], gv[NHMC_VEC_PER_THREAD];
+  bool ok[NHMC_VEC_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    ok[i] = q < n4;
+    if (ok[i]) {
+      xv[i] = x[base + q];
+      pv[i] = p[base + q];
+      gv[i] = g[base + q];
+      if (HAS_G2) {
+        const float4 h = g2[base + q];
+        gv[i].x += h.x; gv[i].y += h.y; gv[i].z += h.z; gv[i].w += h.w;
+      }
+    }
+  }
+
+  float sx = 0.0f, sp = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    if (!ok[i]) continue;
+    float* xe = reinterpret_cast<float*>(&xv[i]);
+    float* pe = reinterpret_cast<float*>(&pv[i]);
+    const float* ge = reinterpret_cast<const float*>(&gv[i]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (MODE == NHMC_LF_FIRST) { sx += xe[c] * xe[c]; sp += pe[c] * pe[c]; }
+      const float G = xe[c] + kf * ge[c];
+      if (MODE == NHMC_LF_FIRST) {
+        pe[c] = pe[c] - eh * G;
+        xe[c] = xe[c] + ex * pe[c];
+      } else if (MODE == NHMC_LF_MID) {
+        pe[c] = pe[c] - ef * G;
+        xe[c] = xe[c] + ex * pe[c];
+      } else {
+        pe[c] = pe[c] - ef * G;
+        pe[c] = pe[c] + eh * G;
+        sx += xe[c] * xe[c];
+        sp += pe[c] * pe[c];
+      }
+    }
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    p[base + q] = pv[i];
+    if (MODE != NHMC_LF_LAST) x[base + q] = xv[i];
+  }
+
+  if (MODE != NHMC_LF_MID) {
+    __shared__ double red[8];
+    double v[2] = {(double)sx, (double)sp};
+    nhmc_block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+      double* dst = sums_ws + ((int64_t)chain * gridDim.x + blockIdx.x) * 2;
+      dst[0] = v[0];
+      dst[1] = v[1];
+    }
+  }
+}
+
+template <int MODE>
+int launch(float* x, float* p, const float* g, const float* g2, const double* eps, const double* sigma_y,
+           double m_inv, int n_chains, int64_t n_elem, double* ws, hipStream_t st) {
+  const int64_t n4 = n_elem / 4;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  if (g2)
+    hipLaunchKernelGGL((k_leapfrog<MODE, true>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
+                       (const float4*)g2, eps, sigma_y, m_inv, n4, ws);
+  else
+    hipLaunchKernelGGL((k_leapfrog<MODE, false>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
+                       (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws);
+  return nhmc_launch_status();
+}
+
+}  // namespace
+
+extern "C" int nhmc_leapfrog_tiles(int64_t n_elem) { return (int)((n_elem + NHMC_TILE - 1) / NHMC_TILE); }
+
+extern "C" size_t nhmc_leapfrog_ws_bytes(int n_chains, int64_t n_elem) {
+  return (size_t)n_chains * (size_t)nhmc_leapfrog_tiles(n_elem) * 2 * sizeof(double);
+}
+
+extern "C" int nhmc_leapfrog_fused(int mode, float* x, float* p, const float* g, const float* g2,
+                                   const double* eps, const double* sigma_y, double m_inv, int n_chains,
+                                   int64_t n_elem, double* sums_ws, nhmc_stream_t stream) {
+  if (!x || !p || !g || !eps || !sigma_y || n_chains <= 0 || n_elem <= 0) return NHMC_ERR_ARG;
+  if (mode != NHMC_LF_MID && !sums_ws) return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || !nhmc_aligned16(x) || !nhmc_aligned16(p) || !nhmc_aligned16(g) || (g2 && !nhmc_aligned16(g2)))
+    return NHMC_ERR_ALIGN;
+  hipStream_t st = nhmc_s(stream);
+  switch (mode) {
+    case NHMC_LF_FIRST: return launch<NHMC_LF_FIRST>(x, p, g, g2, eps, sigma_y, m_inv, n_chains, n_elem, sums_ws, st);
+    case NHMC_LF_MID:   return launch<NHMC_LF_MID>(x, p, g, g2, eps, sigma_y, m_inv, n_chains, n_elem, sums_ws, st);
+    case NHMC_LF_LAST:  return launch<NHMC_LF_LAST>(x, p, g, g2, eps, sigma_y, m_inv, n_chains, n_elem, sums_ws, st);
+    default: return NHMC_ERR_ARG;
+  }
+}

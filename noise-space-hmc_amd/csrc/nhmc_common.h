@@ -1,0 +1,42 @@
+// Shared device/host helpers for libnhmc (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nhmc.h"
+
+#define NHMC_WAVE 64
+#define NHMC_BLOCK 256            // 4 waves, one per SIMD of a CU
+#define NHMC_VEC_PER_THREAD 4     // float4 per thread per stream -> 4096 elements per tile
+#define NHMC_TILE (NHMC_BLOCK * NHMC_VEC_PER_THREAD * 4)
+
+static inline bool nhmc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline hipStream_t nhmc_s(nhmc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int nhmc_launch_status() { return hipGetLastError() == hipSuccess ? NHMC_OK : NHMC_ERR_LAUNCH; }
+
+// Wave-level sum over 64 lanes with shuffles; result valid in lane 0.
+__device__ __forceinline__ double nhmc_wave_sum(double v) {
+#pragma unroll
+  for (int off = NHMC_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, NHMC_WAVE);
+  return v;
+}
+
+// Block-level sum of up to NV values per thread (256 threads = 4 waves): shuffle inside the
+// wave, 4 x NV doubles through LDS, fixed order -> deterministic.  Result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void nhmc_block_sum(double (&v)[NV], double* lds /* [4*NV] */) {
+  const int lane = threadIdx.x & (NHMC_WAVE - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = nhmc_wave_sum(v[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (lds[0 * NV + i] + lds[1 * NV + i]) + (lds[2 * NV + i] + lds[3 * NV + i]);
+  }
+}
+
+__device__ __forceinline__ float nhmc_clip1(float v) { return fminf(fmaxf(v, -1.0f), 1.0f); }
+__device__ __forceinline__ float nhmc_in1(float v) { return (v >= -1.0f && v <= 1.0f) ? 1.0f : 0.0f; }

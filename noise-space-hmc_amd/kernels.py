@@ -1,0 +1,309 @@
+"""Typed torch-tensor front ends of the C ABI (include/nhmc.h).
+
+torch is plumbing here: it owns device memory and the stream; every function below checks its
+operands (device, dtype, contiguity, shape) on the host, then hands raw pointers to libnhmc.so on
+the CURRENT torch stream.  No function allocates inside the library; outputs are torch tensors
+created here.  Nothing falls back to torch arithmetic.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+LF_FIRST, LF_MID, LF_LAST = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None, name='tensor'):
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.NhmcError(f'{name} must live on the GPU (got {t.device}); libnhmc has no CPU path')
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.NhmcError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise _lib.NhmcError(f'{name} must be contiguous')
+    return C.c_void_p(t.data_ptr())
+
+
+def _chains_elems(x):
+    return x.shape[0], x[0].numel()
+
+
+def _f64(v, n, device):
+    """per-chain fp64 scalars: python float / sequence / tensor -> device double[n]"""
+    if isinstance(v, torch.Tensor):
+        if v.dtype != torch.float64 or v.numel() != n:
+            raise _lib.NhmcError('per-chain scalar tensors must be float64 of length n_chains')
+        return v
+    return torch.full((n,), float(v), dtype=torch.float64, device=device) if not hasattr(v, '__len__') \
+        else torch.tensor(list(v), dtype=torch.float64, device=device)
+
+
+# ---- a1-a4 ----------------------------------------------------------------------------------
+def leapfrog_tiles(n_elem):
+    return _lib.load().nhmc_leapfrog_tiles(n_elem)
+
+
+def leapfrog_ws(n_chains, n_elem, device):
+    return torch.empty(n_chains * leapfrog_tiles(n_elem) * 2, dtype=torch.float64, device=device)
+
+
+def leapfrog_fused(mode, x, p, g, eps, sigma_y, m_inv, sums_ws=None, g2=None):
+    """In place on x, p.  eps / sigma_y: float64 device tensors [B] (or python floats)."""
+    lib = _lib.load()
+    B, N = _chains_elems(x)
+    if p.shape != x.shape or g.shape != x.shape or (g2 is not None and g2.shape != x.shape):
+        raise _lib.NhmcError('x, p, g (and g2) must have the same shape')
+    eps, sigma_y = _f64(eps, B, x.device), _f64(sigma_y, B, x.device)
+    if mode != LF_MID and sums_ws is None:
+        raise _lib.NhmcError('FIRST/LAST modes need sums_ws')
+    if sums_ws is not None and sums_ws.numel() < B * leapfrog_tiles(N) * 2:
+        raise _lib.NhmcError('sums_ws too small')
+    rc = lib.nhmc_leapfrog_fused(mode, _p(x, torch.float32, 'x'), _p(p, torch.float32, 'p'),
+                                 _p(g, torch.float32, 'g'), _p(g2, torch.float32, 'g2'),
+                                 _p(eps, torch.float64, 'eps'), _p(sigma_y, torch.float64, 'sigma_y'),
+                                 float(m_inv), B, N, _p(sums_ws, torch.float64, 'sums_ws'), _stream())
+    _lib.check(rc, 'nhmc_leapfrog_fused')
+
+
+# ---- a9-a11 ---------------------------------------------------------------------------------
+def _mix_shapes(xt, e):
+    B, Cc = xt.shape[0], xt.shape[1]
+    hw = xt[0, 0].numel()
+    if e.shape[0] != B or e.shape[2:] != xt.shape[2:]:
+        raise _lib.NhmcError(f'score output shape {tuple(e.shape)} does not match xt {tuple(xt.shape)}')
+    return B, Cc, hw, e.shape[1]
+
+
+def _alpha(a, B, device):
+    a = a.reshape(-1)
+    if a.numel() == 1 and B > 1:
+        a = a.expand(B)
+    if a.numel() != B:
+        raise _lib.NhmcError('alpha-bar must have one entry per chain')
+    return a.to(device=device, dtype=torch.float32).contiguous()
+
+
+def ddim_mix_fwd(xt, e, at, at_next, final_clip=False, want=('xt_next',)):
+    """Returns a dict with the requested outputs among 'xt_next', 'x0_t', 'add_up'."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    out = {k: torch.empty_like(xt) for k in want}
+    rc = lib.nhmc_ddim_mix_fwd(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                               int(final_clip), _p(out.get('xt_next')), _p(out.get('x0_t')), _p(out.get('add_up')),
+                               B, Cc, hw, _stream())
+    _lib.check(rc, 'nhmc_ddim_mix_fwd')
+    return out
+
+
+def ddim_map_back(x0_t, add_up, at_next):
+    lib = _lib.load()
+    B, N = _chains_elems(x0_t)
+    out = torch.empty_like(x0_t)
+    rc = lib.nhmc_ddim_map_back(_p(x0_t, torch.float32, 'x0_t'), _p(add_up, torch.float32, 'add_up'),
+                                _p(_alpha(at_next, B, x0_t.device)), _p(out), B, N, _stream())
+    _lib.check(rc, 'nhmc_ddim_map_back')
+    return out
+
+
+def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None):
+    """-> (g_xt [B,C,H,W], g_e [B,e_channels,H,W])"""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    g_xt, g_e = torch.empty_like(xt), torch.empty_like(e)
+    rc = lib.nhmc_ddim_mix_bwd(_p(gout, torch.float32, 'gout'), _p(gout2, torch.float32, 'gout2'),
+                               _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                               int(final_clip), _p(g_xt), _p(g_e), B, Cc, hw, _stream())
+    _lib.check(rc, 'nhmc_ddim_mix_bwd')
+    return g_xt, g_e
+
+
+# ---- a12-a15 --------------------------------------------------------------------------------
+def sum_partials(ws, tiles, n_chains, stride=1, offset=0):
+    lib = _lib.load()
+    out = torch.empty(n_chains, dtype=torch.float64, device=ws.device)
+    _lib.check(lib.nhmc_sum_partials(_p(ws, torch.float64), tiles, stride, offset, n_chains, _p(out), _stream()),
+               'nhmc_sum_partials')
+    return out
+
+
+def data_inpaint(xt, y, slot, apply_clip=True):
+    """-> (loss [B] float64, g_xt).  slot: int32 [N] CHW map into y (-1 = masked)."""
+    lib = _lib.load()
+    B, N = _chains_elems(xt)
+    M = y.shape[1]
+    if slot.numel() != N or y.shape[0] != B:
+        raise _lib.NhmcError('slot / y shape mismatch')
+    tiles = lib.nhmc_data_tiles(N)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    g = torch.empty_like(xt)
+    rc = lib.nhmc_data_inpaint(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(slot, torch.int32, 'slot'),
+                               int(apply_clip), _p(g), _p(ws), B, N, M, _stream())
+    _lib.check(rc, 'nhmc_data_inpaint')
+    return sum_partials(ws, tiles, B), g
+
+
+def inpaint_H(x, kept_chw):
+    lib = _lib.load()
+    B, N = _chains_elems(x)
+    M = kept_chw.numel()
+    y = torch.empty(B, M, dtype=torch.float32, device=x.device)
+    _lib.check(lib.nhmc_inpaint_H(_p(x, torch.float32, 'x'), _p(kept_chw, torch.int32), _p(y), B, N, M, _stream()),
+               'nhmc_inpaint_H')
+    return y
+
+
+def inpaint_Ht(y, slot, n_elem):
+    lib = _lib.load()
+    B, M = y.shape
+    x = torch.empty(B, n_elem, dtype=torch.float32, device=y.device)
+    _lib.check(lib.nhmc_inpaint_Ht(_p(y, torch.float32, 'y'), _p(slot, torch.int32), _p(x), B, n_elem, M, _stream()),
+               'nhmc_inpaint_Ht')
+    return x
+
+
+def data_sr(xt, y, ratio, apply_clip=True):
+    lib = _lib.load()
+    B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
+    if xt.shape[3] != dim:
+        raise _lib.NhmcError('square images only')
+    tiles = lib.nhmc_sr_tiles(Cc, dim, ratio)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    g = torch.empty_like(xt)
+    rc = lib.nhmc_data_sr(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), ratio, int(apply_clip), _p(g),
+                          _p(ws), B, Cc, dim, _stream())
+    _lib.check(rc, 'nhmc_data_sr')
+    return sum_partials(ws, tiles, B), g
+
+
+def sr_H(x, ratio):
+    lib = _lib.load()
+    B, Cc, dim = x.shape[0], x.shape[1], x.shape[2]
+    y = torch.empty(B, Cc * (dim // ratio) ** 2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.nhmc_sr_H(_p(x, torch.float32, 'x'), _p(y), ratio, B, Cc, dim, _stream()), 'nhmc_sr_H')
+    return y
+
+
+def sr_Ht(y, ratio, channels, dim, scale):
+    lib = _lib.load()
+    B = y.shape[0]
+    x = torch.empty(B, channels * dim * dim, dtype=torch.float32, device=y.device)
+    _lib.check(lib.nhmc_sr_Ht(_p(y, torch.float32, 'y'), _p(x), ratio, float(scale), B, channels, dim, _stream()),
+               'nhmc_sr_Ht')
+    return x
+
+
+def spectral_apply(x, L, R, Dmap, LoT, RoT):
+    """out_c = Lo (D_c o (L^T X_c R)) Ro^T ; x: [B,C,d,d]"""
+    lib = _lib.load()
+    B, Cc, dim = x.shape[0], x.shape[1], x.shape[2]
+    out, tmp = torch.empty_like(x), torch.empty_like(x)
+    rc = lib.nhmc_spectral_apply(_p(x, torch.float32, 'x'), _p(L, torch.float32), _p(R, torch.float32),
+                                 _p(Dmap, torch.float32), _p(LoT, torch.float32), _p(RoT, torch.float32), _p(out),
+                                 _p(tmp), B, Cc, dim, _stream())
+    _lib.check(rc, 'nhmc_spectral_apply')
+    return out
+
+
+def data_spectral(xt, y, factors, Dmap, apply_clip=True):
+    """factors: packed [8,d,d] = U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T -> (loss [B] float64, g_xt)"""
+    lib = _lib.load()
+    B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
+    tiles = lib.nhmc_spectral_tiles(Cc, dim)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    g = torch.empty_like(xt)
+    rc = lib.nhmc_data_spectral(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'),
+                                _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32), int(apply_clip),
+                                _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    _lib.check(rc, 'nhmc_data_spectral')
+    return sum_partials(ws, tiles, B), g
+
+
+# ---- a5-a7 ----------------------------------------------------------------------------------
+def hamiltonian(sums_ws, n_elem, loss, sigma_y, m_inv, want_terms=False):
+    lib = _lib.load()
+    B = loss.numel()
+    H = torch.empty(B, dtype=torch.float32, device=loss.device)
+    terms = torch.empty(B, 3, dtype=torch.float64, device=loss.device) if want_terms else None
+    rc = lib.nhmc_hamiltonian(_p(sums_ws, torch.float64), leapfrog_tiles(n_elem), _p(loss, torch.float64, 'loss'),
+                              _p(_f64(sigma_y, B, loss.device)), float(m_inv), _p(H), _p(terms), B, _stream())
+    _lib.check(rc, 'nhmc_hamiltonian')
+    return (H, terms) if want_terms else H
+
+
+def metropolis(H0, H1, u, active=None):
+    lib = _lib.load()
+    B = H0.numel()
+    acc = torch.empty(B, dtype=torch.int32, device=H0.device)
+    dH = torch.empty(B, dtype=torch.float32, device=H0.device)
+    rc = lib.nhmc_metropolis(_p(H0, torch.float32), _p(H1, torch.float32), _p(u, torch.float32, 'u'),
+                             _p(active, torch.int32), _p(acc), _p(dH), B, _stream())
+    _lib.check(rc, 'nhmc_metropolis')
+    return acc, dH
+
+
+def schedule_begin(state, sigma_0, epochs, sampling):
+    lib = _lib.load()
+    B = state['epoch'].numel()
+    rc = lib.nhmc_schedule_begin(_p(state['epoch'], torch.int32), _p(state['tau'], torch.float64),
+                                 _p(state['eps'], torch.float64), _p(state['sigma_y'], torch.float64),
+                                 _p(state['eps_eff'], torch.float64), _p(state['active'], torch.int32),
+                                 float(sigma_0), epochs, sampling, B, _stream())
+    _lib.check(rc, 'nhmc_schedule_begin')
+
+
+def accept_commit(accept, epoch, x, x_prop, xt_prop, samples, epochs, sampling):
+    lib = _lib.load()
+    B, N = _chains_elems(x)
+    rc = lib.nhmc_accept_commit(_p(accept, torch.int32), _p(epoch, torch.int32), _p(x, torch.float32, 'x'),
+                                _p(x_prop, torch.float32, 'x_prop'), _p(xt_prop, torch.float32, 'xt_prop'),
+                                _p(samples, torch.float32, 'samples'), epochs, sampling, B, N, _stream())
+    _lib.check(rc, 'nhmc_accept_commit')
+
+
+def schedule_end(accept, state):
+    lib = _lib.load()
+    B = accept.numel()
+    rc = lib.nhmc_schedule_end(_p(accept, torch.int32), _p(state['active'], torch.int32),
+                               _p(state['epoch'], torch.int32), _p(state['rejected'], torch.int32),
+                               _p(state['tau'], torch.float64), _p(state['eps'], torch.float64),
+                               _p(state.get('n_accept'), torch.int32), _p(state.get('n_reject'), torch.int32),
+                               B, _stream())
+    _lib.check(rc, 'nhmc_schedule_end')
+
+
+def psnr(xt, x_orig):
+    lib = _lib.load()
+    B, N = _chains_elems(xt)
+    ws = torch.empty(B * lib.nhmc_data_tiles(N), dtype=torch.float64, device=xt.device)
+    out = torch.empty(B, dtype=torch.float32, device=xt.device)
+    _lib.check(lib.nhmc_psnr(_p(xt, torch.float32, 'xt'), _p(x_orig, torch.float32, 'x_orig'), _p(out), _p(ws),
+                             B, N, _stream()), 'nhmc_psnr')
+    return out
+
+
+# ---- a1 -------------------------------------------------------------------------------------
+def randn_philox(shape, seed, chain_id0, draw, scale=1.0, device='cuda', out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+    B, N = _chains_elems(out)
+    _lib.check(lib.nhmc_randn_philox(_p(out, torch.float32), int(seed), int(chain_id0), int(draw), float(scale),
+                                     B, N, _stream()), 'nhmc_randn_philox')
+    return out
+
+
+def uniform_philox(n_chains, seed, chain_id0, draw, device='cuda'):
+    lib = _lib.load()
+    out = torch.empty(n_chains, dtype=torch.float32, device=device)
+    _lib.check(lib.nhmc_uniform_philox(_p(out), int(seed), int(chain_id0), int(draw), n_chains, _stream()),
+               'nhmc_uniform_philox')
+    return out

@@ -1,0 +1,205 @@
+"""Linear forward operators with the reference's `H_functions` surface, on the HIP kernels.
+
+Mirrors obs_functions/Hfuncs.py for the three operators on the HMC hot path -- same constructor
+arguments, same `H / Ht / H_pinv / is_linear`, inputs `[B, ...]`, outputs `[B, flat]` -- but each
+call is one fused kernel (or one MFMA GEMM chain) instead of the reference's SVD-form compositions
+(`U(singulars * Vt(x))`, Hfuncs.py:65-90).  Each class also exposes `data_term(xt, y, apply_clip)`
+-> (loss[B] fp64, d loss/d xt): the fused residual / loss / gradient pass the sampler uses in place
+of `torch.sum((y_0 - H(xt))**2)` + autograd (main_sampling.py:694-695,710-711).
+
+Operator constants (index maps, factor matrices) are built once on the host -- O(N), not the
+reference's O(N*M) Python list comprehension (Hfuncs.py:125) -- and stay resident on the device.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from ._lib import NhmcError
+
+
+def _img(v, channels, dim):
+    B = v.shape[0]
+    return v.reshape(B, channels, dim, dim).contiguous()
+
+
+class H_functions:
+    """Surface of obs_functions/Hfuncs.py:22-116 that the samplers use."""
+
+    def H(self, vec):
+        raise NotImplementedError()
+
+    def Ht(self, vec):
+        raise NotImplementedError()
+
+    def H_pinv(self, vec):
+        raise NotImplementedError()
+
+    def data_term(self, xt, y, apply_clip=True):
+        raise NotImplementedError()
+
+    def is_linear(self):
+        return True
+
+
+class Inpainting(H_functions):
+    """obs_functions/Hfuncs.py:119-154.  `missing_indices` index the HWC-flattened image."""
+
+    def __init__(self, channels, img_dim, missing_indices, device):
+        self.channels, self.img_dim = channels, img_dim
+        n, hw = channels * img_dim ** 2, img_dim ** 2
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[missing_indices.detach().cpu().long()] = False
+        kept_hwc = torch.nonzero(keep).squeeze(1)                 # ascending, as Hfuncs.py:125
+        self.missing_indices = missing_indices
+        self.kept_indices = kept_hwc.to(device)
+        self.M = int(kept_hwc.numel())
+        if self.M == 0:
+            raise NhmcError('inpainting mask keeps no pixel')
+        # HWC index -> CHW address, and the dense CHW -> y-slot map the kernels read
+        kept_chw = (kept_hwc % channels) * hw + kept_hwc // channels
+        slot = torch.full((n,), -1, dtype=torch.int32)
+        slot[kept_chw] = torch.arange(self.M, dtype=torch.int32)
+        self.kept_chw = kept_chw.to(torch.int32).to(device)
+        self.slot = slot.to(device)
+        self._singulars = torch.ones(self.M, device=device)
+
+    def singulars(self):
+        return self._singulars
+
+    def H(self, vec):
+        return K.inpaint_H(_img(vec, self.channels, self.img_dim), self.kept_chw)
+
+    def Ht(self, vec):
+        return K.inpaint_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.slot, self.channels * self.img_dim ** 2)
+
+    H_pinv = Ht
+
+    def data_term(self, xt, y, apply_clip=True):
+        return K.data_inpaint(xt, y, self.slot, apply_clip)
+
+
+class SuperResolution(H_functions):
+    """obs_functions/Hfuncs.py:180-234: r x r block mean, H^T = broadcast / r^2, H^+ = broadcast."""
+
+    def __init__(self, channels, img_dim, ratio, device):
+        assert img_dim % ratio == 0
+        self.channels, self.img_dim, self.ratio = channels, img_dim, ratio
+        self.y_dim = img_dim // ratio
+        self.M = channels * self.y_dim ** 2
+        self.device = device
+
+    def singulars(self):
+        return torch.full((self.M,), 1.0 / self.ratio, device=self.device)
+
+    def H(self, vec):
+        return K.sr_H(_img(vec, self.channels, self.img_dim), self.ratio)
+
+    def Ht(self, vec):
+        return K.sr_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.ratio, self.channels, self.img_dim,
+                       1.0 / self.ratio ** 2)
+
+    def H_pinv(self, vec):
+        return K.sr_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.ratio, self.channels, self.img_dim, 1.0)
+
+    def data_term(self, xt, y, apply_clip=True):
+        return K.data_sr(xt, y, self.ratio, apply_clip)
+
+
+def _band_matrix(kernel, img_dim):
+    """Hfuncs.py:459-471.  The reference's range(i - k//2, i + k//2) is half-open: a 9-tap kernel uses 8 taps."""
+    k = kernel.shape[0]
+    Hs = torch.zeros(img_dim, img_dim)
+    idx = torch.arange(img_dim)
+    for tap in range(2 * (k // 2)):
+        j = idx + tap - k // 2
+        ok = (j >= 0) & (j < img_dim)
+        Hs[idx[ok], j[ok]] = kernel[tap]
+    return Hs
+
+
+class Deblurring2D(H_functions):
+    """obs_functions/Hfuncs.py:448-523, carried as data: U1,U2,V1,V2 [d,d] and D [C,d,d].
+
+    The reference tiles the sorted singular values (:519-520) while its Vt() interleaves channels
+    (:493-499); the operator it really computes is out_c = U1 (D_c o (V1^T X_c V2)) U2^T with
+    D_c[perm[k]] = s_sorted[(3k+c) mod d^2].  `__init__` rebuilds that from the two 1-D kernels
+    (stable sort, so the instance is reproducible); `from_factors` takes exported operator data.
+    """
+
+    def __init__(self, kernel1, kernel2, channels, img_dim, device, zero=3e-2):
+        H1, H2 = _band_matrix(kernel1.detach().cpu().float(), img_dim), _band_matrix(kernel2.detach().cpu().float(), img_dim)
+        U1, s1, V1h = torch.linalg.svd(H1)
+        U2, s2, V2h = torch.linalg.svd(H2)
+        s1 = torch.where(s1 < zero, torch.zeros_like(s1), s1)
+        s2 = torch.where(s2 < zero, torch.zeros_like(s2), s2)
+        prod = torch.outer(s1, s2).reshape(-1)
+        s_sorted, perm = prod.sort(descending=True, stable=True)
+        hw = img_dim * img_dim
+        k = torch.arange(hw)
+        D = torch.zeros(channels, hw)
+        for c in range(channels):
+            D[c, perm] = s_sorted[(channels * k + c) % hw]
+        self._init_factors(U1, U2, V1h.t().contiguous(), V2h.t().contiguous(), D.reshape(channels, img_dim, img_dim), device)
+
+    @classmethod
+    def from_factors(cls, U1, U2, V1, V2, D, device):
+        self = cls.__new__(cls)
+        self._init_factors(U1, U2, V1, V2, D, device)
+        return self
+
+    def _init_factors(self, U1, U2, V1, V2, D, device):
+        self.channels, self.img_dim = D.shape[0], D.shape[1]
+        if self.img_dim % 32:
+            raise NhmcError('spectral operator needs img_dim % 32 == 0')
+        self.M = D.numel()
+        mats = [m.detach().cpu().float() for m in (U1, U2, V1, V2)]
+        # both orientations resident: "multiply from the left by M" reads M^T's memory (k-major MFMA tiles)
+        self.factors = torch.stack(mats + [m.t().contiguous() for m in mats]).contiguous().to(device)
+        self.Dmap = D.detach().cpu().float().contiguous().to(device)
+        Dp = torch.where(self.Dmap != 0, 1.0 / self.Dmap, torch.zeros_like(self.Dmap))
+        self.Dpinv = Dp.contiguous()
+
+    def _f(self, i):
+        return self.factors[i]
+
+    # indices into self.factors: U1 0, U2 1, V1 2, V2 3, U1^T 4, U2^T 5, V1^T 6, V2^T 7
+    def H(self, vec):
+        x = _img(vec, self.channels, self.img_dim)
+        return K.spectral_apply(x, self._f(2), self._f(3), self.Dmap, self._f(4), self._f(5)).reshape(x.shape[0], -1)
+
+    def Ht(self, vec):
+        y = _img(vec, self.channels, self.img_dim)
+        return K.spectral_apply(y, self._f(0), self._f(1), self.Dmap, self._f(6), self._f(7)).reshape(y.shape[0], -1)
+
+    def H_pinv(self, vec):
+        y = _img(vec, self.channels, self.img_dim)
+        return K.spectral_apply(y, self._f(0), self._f(1), self.Dpinv, self._f(6), self._f(7)).reshape(y.shape[0], -1)
+
+    def data_term(self, xt, y, apply_clip=True):
+        return K.data_spectral(xt, y.reshape(xt.shape).contiguous(), self.factors, self.Dmap, apply_clip)
+
+
+def gaussian_taps(sigma, half=4):
+    """main_sampling.py:327-335."""
+    k = torch.tensor([math.exp(-0.5 * (x / sigma) ** 2) for x in range(-half, half + 1)], dtype=torch.float32)
+    return k / k.sum()
+
+
+def build_operator(deg, channels, img_dim, device, generator=None):
+    """`prepare_measurement` (main_sampling.py:261-351) for the degradations on the HMC hot path."""
+    if deg.startswith('sr') and deg[2:].isdigit():
+        return SuperResolution(channels, img_dim, int(deg[2:]), device)
+    if deg == 'inpaint_random':
+        hw = img_dim * img_dim
+        r = 3 * torch.randperm(hw, generator=generator)[: int(hw * 0.92)].long()       # :302-305
+        return Inpainting(channels, img_dim, torch.cat([r, r + 1, r + 2]), device)
+    if deg == 'inpaint_box':
+        import random
+        missing = torch.zeros(img_dim, img_dim, channels)
+        left, up = random.randint(16, 112), random.randint(16, 112)                     # :292-296
+        missing[left:left + 128, up:up + 128, :] = 1.0
+        return Inpainting(channels, img_dim, torch.nonzero(missing.view(-1)).squeeze(1), device)
+    if deg == 'deblur_aniso':
+        return Deblurring2D(gaussian_taps(1.0), gaussian_taps(20.0), channels, img_dim, device)
+    raise NotImplementedError(f'degradation {deg!r} is outside the HMC hot path of this build')

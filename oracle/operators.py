@@ -1,0 +1,170 @@
+"""Oracle: linear forward operators (test infrastructure, see oracle/__init__.py).
+
+The reference writes every operator in SVD form, H = U diag(s) V^T, and applies
+it as `U(s * Vt(x)[:, :len(s)])` (obs_functions/Hfuncs.py:65-71), H^T as
+`V(add_zeros(s * Ut(y)))` (:73-79) and H^+ with 1/s on the non-zero singular
+values (:81-90).  This file restates WHAT those compositions compute for the
+three operators on the hot path, in plain fp32 torch-CPU ops:
+
+  InpaintRef      Hfuncs.py:119-154  gather of the HWC-interleaved image at the
+                                     ascending kept indices; H^T = H^+ = scatter
+  BlockMeanRef    Hfuncs.py:180-234  r x r block mean, output flattened CHW;
+                                     H^T = nearest-upsample / r^2, H^+ = nearest-upsample
+  SpectralBlurRef Hfuncs.py:448-523  Y_c = U1 (D_c o (V1^T X_c V2)) U2^T with the
+                                     per-channel multiplier map D_c the reference's
+                                     tiled-singulars / interleaved-Vt layout produces
+
+All take [B,C,H,W] (or anything reshapeable to it) and return [B, M] for H and
+[B, C*H*W] for H^T / H^+, like the reference.
+"""
+import math
+import torch
+
+
+class InpaintRef:
+    """Hfuncs.py:119-154.  `missing` are indices into the HWC-flattened image.
+
+    Vt() permutes CHW -> HWC and moves kept entries first (:134-139); the
+    singular values are all 1 (:123); U is the identity (:141-145).  Hence
+    H(x)[k] = x_hwc[kept[k]] with kept ascending (:125).
+    """
+
+    def __init__(self, channels, img_dim, missing):
+        self.channels, self.img_dim = channels, img_dim
+        n = channels * img_dim * img_dim
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[missing.long().cpu()] = False
+        self.kept = torch.nonzero(keep).squeeze(1)      # ascending, int64
+        self.missing = missing.long().cpu()
+        self.M = int(self.kept.numel())
+
+    def _hwc(self, x):
+        B = x.shape[0]
+        return x.reshape(B, self.channels, -1).permute(0, 2, 1).reshape(B, -1)
+
+    def H(self, x):
+        return self._hwc(x)[:, self.kept]
+
+    def Ht(self, y):
+        B = y.shape[0]
+        hwc = torch.zeros(B, self.channels * self.img_dim ** 2, dtype=y.dtype)
+        hwc[:, self.kept] = y.reshape(B, -1)
+        return hwc.reshape(B, -1, self.channels).permute(0, 2, 1).reshape(B, -1)
+
+    H_pinv = Ht          # all singular values are 1
+
+
+class BlockMeanRef:
+    """Hfuncs.py:180-234 (SuperResolution).
+
+    SVD of the 1 x r^2 row [1/r^2]*r^2 (:187-188): s = 1/r, V[:,0] = +-1/r, U = +-1.
+    Vt() extracts r x r patches and keeps the first coefficient of each (:206-219),
+    so H(x) = U00 * (1/r) * sum_i(V[i,0] * patch_i) = block mean, laid out
+    [c, i, j] (CHW).  H^T spreads y/r^2 over the block, H^+ spreads y.
+    """
+
+    def __init__(self, channels, img_dim, ratio):
+        assert img_dim % ratio == 0
+        self.channels, self.img_dim, self.ratio = channels, img_dim, ratio
+        self.y_dim = img_dim // ratio
+        self.M = channels * self.y_dim ** 2
+
+    def H(self, x):
+        B, r, d = x.shape[0], self.ratio, self.y_dim
+        blocks = x.reshape(B, self.channels, d, r, d, r)
+        return blocks.sum(dim=(3, 5)).mul(1.0 / (r * r)).reshape(B, -1)
+
+    def _up(self, y, scale):
+        B, r, d = y.shape[0], self.ratio, self.y_dim
+        img = y.reshape(B, self.channels, d, 1, d, 1).expand(B, self.channels, d, r, d, r)
+        return (img * scale).reshape(B, -1)
+
+    def Ht(self, y):
+        return self._up(y, 1.0 / (self.ratio ** 2))
+
+    def H_pinv(self, y):
+        return self._up(y, 1.0)
+
+
+def band_matrix(kernel, img_dim):
+    """Hfuncs.py:459-471: 1-D convolution matrix.  The reference's loop runs
+    j in [i - k//2, i + k//2) -- the upper bound is exclusive, so a 9-tap kernel
+    contributes only its first 8 taps."""
+    k = kernel.shape[0]
+    Hs = torch.zeros(img_dim, img_dim)
+    for i in range(img_dim):
+        for j in range(i - k // 2, i + k // 2):
+            if 0 <= j < img_dim:
+                Hs[i, j] = kernel[j - i + k // 2]
+    return Hs
+
+
+def gaussian_taps(sigma, half=4):
+    """main_sampling.py:327-335: exp(-0.5 (x/sigma)^2) for x in -4..4, normalised."""
+    taps = torch.tensor([math.exp(-0.5 * (x / sigma) ** 2) for x in range(-half, half + 1)],
+                        dtype=torch.float32)
+    return taps / taps.sum()
+
+
+class SpectralBlurRef:
+    """Hfuncs.py:448-523 (Deblurring2D), carried as DATA.
+
+    Fields: U1,U2,V1,V2 [d,d] and D [C,d,d].  kernel1 acts along rows (height,
+    left-multiply), kernel2 along width (right-multiply) (:486-487).
+
+    `singulars()` tiles the sorted products 3x (:519-520) while Vt() interleaves
+    channels (:493-499), so spectral position perm[k] of channel c is multiplied
+    by s_sorted[(3k+c) mod d^2]; `from_kernels` builds that map.
+    """
+
+    def __init__(self, U1, U2, V1, V2, D):
+        self.U1, self.U2, self.V1, self.V2, self.D = U1, U2, V1, V2, D
+        self.channels, self.img_dim = D.shape[0], D.shape[1]
+        self.M = D.numel()
+
+    @classmethod
+    def from_kernels(cls, kernel1, kernel2, channels, img_dim, zero=3e-2, stable=False):
+        H1, H2 = band_matrix(kernel1, img_dim), band_matrix(kernel2, img_dim)
+        U1, s1, V1 = torch.svd(H1, some=False)
+        U2, s2, V2 = torch.svd(H2, some=False)
+        s1 = torch.where(s1 < zero, torch.zeros_like(s1), s1)     # :475-477
+        s2 = torch.where(s2 < zero, torch.zeros_like(s2), s2)
+        prod = torch.matmul(s1.reshape(img_dim, 1), s2.reshape(1, img_dim)).reshape(-1)
+        s_sorted, perm = prod.sort(descending=True, stable=stable)  # :481 (unstable there)
+        return cls(U1, U2, V1, V2, cls.multiplier_map(s_sorted, perm, channels, img_dim))
+
+    @staticmethod
+    def multiplier_map(s_sorted, perm, channels, img_dim):
+        hw = img_dim * img_dim
+        k = torch.arange(hw)
+        D = torch.zeros(channels, hw, dtype=s_sorted.dtype)
+        for c in range(channels):
+            D[c, perm] = s_sorted[(channels * k + c) % hw]
+        return D.reshape(channels, img_dim, img_dim)
+
+    def _img(self, v):
+        return v.reshape(v.shape[0], self.channels, self.img_dim, self.img_dim)
+
+    def _sandwich(self, L, X, R, Dmap, Lo, Ro):
+        spec = torch.matmul(torch.matmul(L.t(), X), R) * Dmap
+        return torch.matmul(torch.matmul(Lo, spec), Ro.t())
+
+    def H(self, x):
+        X = self._img(x)
+        return self._sandwich(self.V1, X, self.V2, self.D, self.U1, self.U2).reshape(X.shape[0], -1)
+
+    def Ht(self, y):
+        Y = self._img(y)
+        return self._sandwich(self.U1, Y, self.U2, self.D, self.V1, self.V2).reshape(Y.shape[0], -1)
+
+    def H_pinv(self, y):
+        Y = self._img(y)
+        Dp = torch.where(self.D != 0, 1.0 / self.D, torch.zeros_like(self.D))
+        return self._sandwich(self.U1, Y, self.U2, Dp, self.V1, self.V2).reshape(Y.shape[0], -1)
+
+
+def random_inpaint_missing(img_dim, frac=0.92, generator=None):
+    """main_sampling.py:302-305: whole RGB triples at randperm(H*W)[:0.92 H*W]."""
+    hw = img_dim * img_dim
+    r = 3 * torch.randperm(hw, generator=generator)[: int(hw * frac)].long()
+    return torch.cat([r, r + 1, r + 2], dim=0)

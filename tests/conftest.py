@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope='session')
+def tiny_score():
+    import torch
+    from oracle.tiny_score import TinyScore
+    net = TinyScore()
+    net.load_state_dict(torch.load(os.path.join(GOLDEN, 'tiny_score.pt'), weights_only=True))
+    return net.eval().requires_grad_(False)
