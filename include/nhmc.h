@@ -92,9 +92,12 @@ int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const float* at_n
  *   g_xt = ((gin*sqrt(at_next)) * 1[-1<=u<=1]) / sqrt(at)
  *   g_e[:, :C] = sqrt(1-at_next)*gin + (-g_xt)*sqrt(1-at);   g_e[:, C:] = 0
  * g_e has e_channels channels (what the score network's backward consumes).
+ * g_x0 (nullable; then gout2 == NULL and final_clip == 0): split form for the plugin surface,
+ * where cal_x0 and map_back are differentiated separately -- gout is then d/d add_up and g_x0
+ * replaces gin*sqrt(at_next) as the gradient reaching x0_t.
  * ---------------------------------------------------------------------------------- */
-int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* xt, const float* e,
-                      int e_channels, const float* at, const float* at_next, int final_clip,
+int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* g_x0, const float* xt,
+                      const float* e, int e_channels, const float* at, const float* at_next, int final_clip,
                       float* g_xt, float* g_e,
                       int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
 

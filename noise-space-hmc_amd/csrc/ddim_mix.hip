@@ -80,9 +80,10 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_map_back(
   }
 }
 
-template <bool HAS_G2>
+template <bool HAS_G2, bool SPLIT>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
-    const float4* __restrict__ gout, const float4* __restrict__ gout2, const float4* __restrict__ xt,
+    const float4* __restrict__ gout, const float4* __restrict__ gout2, const float4* __restrict__ g_x0,
+    const float4* __restrict__ xt,
     const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
     const float* __restrict__ at_next, int final_clip, float4* __restrict__ g_xt, float4* __restrict__ g_e,
     int64_t n4) {
@@ -90,12 +91,13 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
   const Coef k = coef(at, at_next, chain);
   const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
   const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
-  float4 gv[NHMC_VEC_PER_THREAD], xv[NHMC_VEC_PER_THREAD], ev[NHMC_VEC_PER_THREAD];
+  float4 gv[NHMC_VEC_PER_THREAD], xv[NHMC_VEC_PER_THREAD], ev[NHMC_VEC_PER_THREAD], sv[NHMC_VEC_PER_THREAD];
 #pragma unroll
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     if (q < n4) {
       gv[i] = gout[base + q]; xv[i] = xt[base + q]; ev[i] = e[ebase + q];
+      if (SPLIT) sv[i] = g_x0[base + q];
       if (HAS_G2) {
         const float4 h = gout2[base + q];
         gv[i].x += h.x; gv[i].y += h.y; gv[i].z += h.z; gv[i].w += h.w;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
     const float* ge = reinterpret_cast<const float*>(&gv[i]);
     const float* xe = reinterpret_cast<const float*>(&xv[i]);
     const float* ee = reinterpret_cast<const float*>(&ev[i]);
+    const float* se = reinterpret_cast<const float*>(&sv[i]);
     float* gx = reinterpret_cast<float*>(&ox);
     float* gee = reinterpret_cast<float*>(&oe);
 #pragma unroll
@@ -117,7 +120,9 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
       const float u = (xe[c] - ee[c] * k.c1) / k.c2;
       float gin = ge[c];
       if (final_clip) gin = gin * nhmc_in1(k.c3 * nhmc_clip1(u) + k.c4 * ee[c]);
-      const float gu = ((gin * k.c3) * nhmc_in1(u)) / k.c2;
+      // fused step: the gradient reaching x0 is gin*c3 (map_back); split surface: it is handed in
+      const float g0 = SPLIT ? se[c] : gin * k.c3;
+      const float gu = (g0 * nhmc_in1(u)) / k.c2;
       gx[c] = gu;
       gee[c] = k.c4 * gin + (-gu) * k.c1;
     }
@@ -184,26 +189,27 @@ extern "C" int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const 
   return nhmc_launch_status();
 }
 
-extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* xt, const float* e,
-                                 int e_channels, const float* at, const float* at_next, int final_clip,
+extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* g_x0, const float* xt,
+                                 const float* e, int e_channels, const float* at, const float* at_next, int final_clip,
                                  float* g_xt, float* g_e, int n_chains, int channels, int64_t hw,
                                  nhmc_stream_t stream) {
   if (!gout || !xt || !e || !at || !at_next || !g_xt || !g_e) return NHMC_ERR_ARG;
   if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
   const int64_t n_elem = (int64_t)channels * hw;
-  if ((n_elem & 3) || !nhmc_aligned16(gout) || !nhmc_aligned16(gout2) || !nhmc_aligned16(xt) ||
+  if (g_x0 && (gout2 || final_clip)) return NHMC_ERR_ARG;
+  if ((n_elem & 3) || !nhmc_aligned16(gout) || !nhmc_aligned16(gout2) || !nhmc_aligned16(g_x0) || !nhmc_aligned16(xt) ||
       !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e))
     return NHMC_ERR_ALIGN;
   const int64_t n4 = n_elem / 4, es4 = (int64_t)e_channels * hw / 4;
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
   hipStream_t st = nhmc_s(stream);
-  if (gout2)
-    hipLaunchKernelGGL((k_mix_bwd<true>), grid, block, 0, st, (const float4*)gout, (const float4*)gout2,
-                       (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, (float4*)g_xt,
-                       (float4*)g_e, n4);
-  else
-    hipLaunchKernelGGL((k_mix_bwd<false>), grid, block, 0, st, (const float4*)gout, (const float4*)nullptr,
-                       (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, (float4*)g_xt,
-                       (float4*)g_e, n4);
+#define NHMC_BWD(G2, SP)                                                                                  \
+  hipLaunchKernelGGL((k_mix_bwd<G2, SP>), grid, block, 0, st, (const float4*)gout, (const float4*)gout2,     \
+                     (const float4*)g_x0, (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, \
+                     (float4*)g_xt, (float4*)g_e, n4)
+  if (g_x0) NHMC_BWD(false, true);
+  else if (gout2) NHMC_BWD(true, false);
+  else NHMC_BWD(false, false);
+#undef NHMC_BWD
   return nhmc_launch_status();
 }

@@ -42,8 +42,9 @@ __global__ void k_metropolis(const float* __restrict__ H0, const float* __restri
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_chains) return;
   const float d = H1[c] - H0[c];
-  // min(1, exp(-dH)); a NaN dH rejects (comparison false), as `u < nan` does in the reference
-  const float ratio = fminf(1.0f, expf(-d));
+  // min(1, exp(-dH)).  Deliberate deviation: a NaN dH REJECTS here.  (In the reference Python's
+  // min(tensor(1), tensor(nan)) returns 1, so a NaN proposal would be accepted and poison the chain.)
+  const float ratio = (d != d) ? 0.0f : fminf(1.0f, expf(-d));
   const bool act = active ? active[c] != 0 : true;
   accept[c] = (act && (u[c] < ratio)) ? 1 : 0;
   if (dH) dH[c] = d;

@@ -112,14 +112,14 @@ def ddim_map_back(x0_t, add_up, at_next):
     return out
 
 
-def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None):
-    """-> (g_xt [B,C,H,W], g_e [B,e_channels,H,W])"""
+def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=None):
+    """-> (g_xt [B,C,H,W], g_e [B,e_channels,H,W]).  g_x0: split form (gout is then d/d add_up)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     g_xt, g_e = torch.empty_like(xt), torch.empty_like(e)
     rc = lib.nhmc_ddim_mix_bwd(_p(gout, torch.float32, 'gout'), _p(gout2, torch.float32, 'gout2'),
-                               _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                               _p(g_x0, torch.float32, 'g_x0'), _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                int(final_clip), _p(g_xt), _p(g_e), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd')
     return g_xt, g_e

@@ -1,0 +1,292 @@
+"""Noise-space HMC sampler: `hmc(...)` with the reference signature, on the HIP kernels.
+
+Replaces main_sampling.py:660-774 (`hmc`) and :898-915 (`iterative_sampling`).  What changes:
+
+  * B independent chains per call (the reference raises for n > 1, main_sampling.py:719): per-chain
+    loss, Hamiltonian, accept test, epoch counter, sigma_y / eps / tau and reject counter, all chains
+    advancing one trajectory per iteration.  At n = 1 it takes the reference's decisions.
+  * One trajectory is sync-free: schedule, momentum draw, L x (decode + gradient + fused update),
+    both Hamiltonians, Metropolis test, accept commit and sample collection are kernels on the
+    stream; the host reads back one small status vector per trajectory (termination test / logging).
+  * The decode's autograd is unrolled by hand: the score network is the only autograd graph; the DDIM
+    mix, the final clip, the operator and the residual are closed-form kernels forward and backward,
+    and the two gradient contributions reaching a DDIM input (direct + through the score network) are
+    summed inside the next kernel instead of by a separate add.
+
+The score network itself stays a PyTorch-ROCm module (north_star): `algo.model(xt, t)`.
+"""
+import math
+import os
+from types import SimpleNamespace
+
+import torch
+
+from . import kernels as K
+from .plugin import HMC
+from .schedule import compute_alpha
+
+
+# --------------------------------------------------------------------------------------------- #
+# reference-surface decode (kept for plugins that only implement cal_x0 / map_back)
+# --------------------------------------------------------------------------------------------- #
+def iterative_sampling(xt, n, b, seq, seq_next, algo, opt, y_0, tqdm_disable=True):
+    """main_sampling.py:898-915, through the plugin surface."""
+    for i, j in zip(reversed(seq), reversed(seq_next)):
+        t = (torch.ones(n) * i).to(xt.device)
+        next_t = (torch.ones(n) * j).to(xt.device)
+        at = compute_alpha(b, t.long())
+        at_next = compute_alpha(b, next_t.long())
+        x0_t, add_up = algo.cal_x0(xt, t, at, at_next, y_0, getattr(opt, 'noise', 'ddpm'))
+        xt = algo.map_back(x0_t, y_0, add_up, at_next, at)
+    return xt
+
+
+# --------------------------------------------------------------------------------------------- #
+# noise sources
+# --------------------------------------------------------------------------------------------- #
+class TorchNoise:
+    """The reference's draws: device randn for the momentum (main_sampling.py:692), CPU rand for the
+    accept uniform (:720) -- one uniform per chain."""
+
+    def momentum(self, it, like, scale):
+        return torch.randn_like(like) * scale
+
+    def uniform(self, it, n, device):
+        return torch.rand(n).to(device)
+
+
+class PhiloxNoise:
+    """Counter-based Philox4x32-10 keyed by (seed, global chain id, draw): a chain's noise does not
+    depend on how chains are split over launches or ranks."""
+
+    def __init__(self, seed, chain_id0=0):
+        self.seed, self.chain_id0 = int(seed), int(chain_id0)
+
+    def momentum(self, it, like, scale):
+        return K.randn_philox(like.shape, self.seed, self.chain_id0, it, scale=scale, device=like.device)
+
+    def uniform(self, it, n, device):
+        return K.uniform_philox(n, self.seed, self.chain_id0, it, device=device)
+
+
+class TapeNoise:
+    """Momenta / uniforms supplied by the caller (parity tests): p(it) -> [B,C,H,W], u(it) -> [B]."""
+
+    def __init__(self, p, u):
+        self.p, self.u = p, u
+
+    def momentum(self, it, like, scale):
+        return (self.p(it).to(like.device) * scale).contiguous()
+
+    def uniform(self, it, n, device):
+        return self.u(it).to(device=device, dtype=torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------- #
+# engine
+# --------------------------------------------------------------------------------------------- #
+class LeapfrogEngine:
+    """Decode + data term + hand-unrolled backward for one ladder of DDIM steps.
+
+    score      callable (xt, t) -> [B, C or 2C, H, W], differentiable w.r.t. xt (a torch module)
+    operator   object with data_term(xt, y, apply_clip) -> (loss[B] fp64, g_xt)   (nhmc.operators)
+    b          betas, fp32 [T] on the device
+    chunk      chains per score-network call (activation memory of 3 graphs scales with it)
+    """
+
+    def __init__(self, score, operator, b, seq, seq_next, device, chunk=None):
+        self.score, self.operator, self.device, self.chunk = score, operator, device, chunk
+        steps = list(zip(reversed(seq), reversed(seq_next)))
+        idx = torch.tensor([[i + 1, j + 1] for i, j in steps], device=b.device)
+        from .schedule import alpha_bar_table
+        table = alpha_bar_table(b)
+        self.t_values = [float(i) for i, _ in steps]
+        self.at = [table[idx[s, 0]].reshape(1).to(device) for s in range(len(steps))]
+        self.at_next = [table[idx[s, 1]].reshape(1).to(device) for s in range(len(steps))]
+        self.n_steps = len(steps)
+
+    def _chunks(self, B):
+        c = self.chunk or B
+        return [(s, min(B, s + c)) for s in range(0, B, c)]
+
+    def decode_and_grad(self, x, y):
+        """-> xt [B,C,H,W] (clipped decode), loss [B] fp64, (g_direct, g_score): the two pieces of
+        d(sum_b loss_b)/dx, summed later inside the consuming kernel."""
+        B = x.shape[0]
+        xt_out = torch.empty_like(x)
+        ga, gb = torch.empty_like(x), torch.empty_like(x)
+        loss = torch.empty(B, dtype=torch.float64, device=x.device)
+        for lo, hi in self._chunks(B):
+            self._decode_and_grad_chunk(x[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi], ga[lo:hi], gb[lo:hi])
+        return xt_out, loss, ga, gb
+
+    def _decode_and_grad_chunk(self, x, y, xt_out, loss_out, ga_out, gb_out):
+        n = x.shape[0]
+        S = self.n_steps
+        ins, outs = [], []
+        cur = x
+        for s in range(S):
+            leaf = cur.detach().requires_grad_(True)
+            t = torch.full((n,), self.t_values[s], device=x.device)
+            with torch.enable_grad():
+                e = self.score(leaf, t)
+            e_c = e.detach() if e.is_contiguous() else e.detach().contiguous()
+            cur = K.ddim_mix_fwd(leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
+                                 final_clip=(s == S - 1))['xt_next']
+            ins.append((leaf, e_c))
+            outs.append(e)
+        xt_out.copy_(cur)
+        # the final clip is applied by the last mix; its mask is re-derived inside the last mix backward
+        l, g = self.operator.data_term(cur, y, apply_clip=False)
+        loss_out.copy_(l)
+        g2 = None
+        for s in reversed(range(S)):
+            leaf, e_c = ins[s]
+            g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
+                                           final_clip=(s == S - 1), gout2=g2)
+            (g_score,) = torch.autograd.grad(outs[s], leaf, g_e)
+            outs[s] = None
+            g, g2 = g_direct, g_score.contiguous()
+        ga_out.copy_(g)
+        gb_out.copy_(g2)
+
+    @torch.no_grad()
+    def decode(self, x):
+        """Forward only (no gradient): the clipped decode."""
+        cur = x
+        n, S = x.shape[0], self.n_steps
+        for s in range(S):
+            t = torch.full((n,), self.t_values[s], device=x.device)
+            e = self.score(cur, t).contiguous()
+            cur = K.ddim_mix_fwd(cur, e, self.at[s].expand(n), self.at_next[s].expand(n), final_clip=(s == S - 1))['xt_next']
+        return cur
+
+
+class ChainState:
+    """Per-chain sampler state, resident on the device (row a7)."""
+
+    FIELDS_I32 = ('epoch', 'rejected', 'active', 'n_accept', 'n_reject')
+    FIELDS_F64 = ('tau', 'eps', 'sigma_y', 'eps_eff')
+
+    def __init__(self, n, tau, eps, device):
+        self.t = {k: torch.zeros(n, dtype=torch.int32, device=device) for k in self.FIELDS_I32}
+        self.t.update({k: torch.zeros(n, dtype=torch.float64, device=device) for k in self.FIELDS_F64})
+        self.t['tau'].fill_(tau)
+        self.t['eps'].fill_(eps)
+        self.t['sigma_y'].fill_(1.0)
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+    def get(self, k, default=None):
+        return self.t.get(k, default)
+
+
+def run_trajectory(engine, x, p, y, state, m, L, ws=None):
+    """One outer iteration (main_sampling.py:693-718) for all chains.  x is NOT modified.
+    -> dict(x_prop, p, xt, loss, H0, H1)"""
+    B, N = x.shape[0], x[0].numel()
+    m_inv = m ** (-1)
+    eps, sig = state['eps_eff'], state['sigma_y']
+    ws = ws if ws is not None else K.leapfrog_ws(B, N, x.device)
+    xt, loss, ga, gb = engine.decode_and_grad(x, y)
+    x_prop = x.clone()
+    K.leapfrog_fused(K.LF_FIRST, x_prop, p, ga, eps, sig, m_inv, ws, g2=gb)
+    H0 = K.hamiltonian(ws, N, loss, sig, m_inv)
+    for l in range(L):
+        xt, loss, ga, gb = engine.decode_and_grad(x_prop, y)
+        K.leapfrog_fused(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, p, ga, eps, sig, m_inv, ws, g2=gb)
+    H1 = K.hamiltonian(ws, N, loss, sig, m_inv)
+    return dict(x_prop=x_prop, p=p, xt=xt, loss=loss, H0=H0, H1=H1)
+
+
+def hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, epochs=60, sampling=20,
+               chunk=None, max_iters=None, log=None, collect_trace=False):
+    """Per-chain HMC for B = x.shape[0] chains.  Returns a SimpleNamespace:
+        samples [B, sampling, C, H, W]   accepted decodes of epochs epochs+sampling .. epochs+2*sampling-1
+        x       [B, C, H, W]             final noise-space positions
+        n_accept, n_reject, epoch [B]    int32
+        psnr    [B] or None              PSNR of the last accepted decode against x_orig
+        iters   int                      trajectories run
+        trace   list of dicts (dH, accept, epoch per iteration) when collect_trace
+    """
+    device = x.device
+    B, N = x.shape[0], x[0].numel()
+    tau, epsilon, m = float(opt.tau), float(opt.epsilon), float(getattr(opt, 'm', 1.0))
+    sigma_0 = float(opt.sigma_0)
+    L = max(1, math.floor(tau / epsilon))                                   # :664, fixed for the run
+    total = epochs + 2 * sampling
+    noise = noise or TorchNoise()
+    operator = H_funcs if hasattr(H_funcs, 'data_term') else None
+    if operator is None:
+        raise TypeError('H_funcs must be an nhmc.operators operator (needs the fused data_term); '
+                        'wrap other linear operators before calling hmc()')
+    score = algo.score if hasattr(algo, 'score') else algo.model
+    engine = LeapfrogEngine(score, operator, b, seq, seq_next, device, chunk=chunk)
+    x = x.detach().clone().contiguous()
+    y_0 = y_0.contiguous()
+    state = ChainState(B, tau, epsilon, device)
+    samples = torch.zeros((B, sampling) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
+    xt_last = torch.zeros_like(x)
+    ws = K.leapfrog_ws(B, N, device)
+    trace = [] if collect_trace else None
+    it = 0
+    while True:
+        K.schedule_begin(state, sigma_0, epochs, sampling)
+        p = noise.momentum(it, x, math.sqrt(m))
+        out = run_trajectory(engine, x, p, y_0, state, m, L, ws)
+        u = noise.uniform(it, B, device)
+        accept, dH = K.metropolis(out['H0'], out['H1'], u, state['active'])
+        K.accept_commit(accept, state['epoch'], x, out['x_prop'], out['xt'], samples, epochs, sampling)
+        K.accept_commit(accept, state['epoch'], xt_last, out['xt'], None, None, epochs, sampling)
+        epoch_before = state['epoch'].clone() if (collect_trace or log) else None
+        K.schedule_end(accept, state)
+        it += 1
+        # the one host read per trajectory: termination (and optional logging)
+        status = torch.stack([state['epoch'], accept]).cpu()
+        if collect_trace:
+            trace.append(dict(dH=dH.cpu(), accept=status[1].clone(), epoch=epoch_before.cpu(),
+                              sigma_y=state['sigma_y'].cpu().clone(), eps=state['eps'].cpu().clone()))
+        if log is not None:
+            log(it, status, state, out, x_orig)
+        if int(status[0].min()) >= total or (max_iters is not None and it >= max_iters):
+            break
+    psnr = K.psnr(xt_last, x_orig.contiguous()) if x_orig is not None else None
+    return SimpleNamespace(samples=samples, x=x, n_accept=state['n_accept'], n_reject=state['n_reject'],
+                           epoch=state['epoch'], psnr=psnr, iters=it, trace=trace, xt=xt_last, L=L)
+
+
+def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
+    """Reference entry point (main_sampling.py:660, called at :483).
+
+    n == 1: returns torch.stack of the 20 collected decodes, [20, C, H, W] -- what the reference returns.
+    n  > 1: (the reference raises) returns [n, 20, C, H, W].
+    Side effects kept: one stdout line per accepted epoch of chain 0 ('epoch', PSNR, sigma_y, tau) unless
+    opt.quiet; the per-epoch PNGs are written only when opt.save_images is set (default off: encoding
+    a PNG per accept was a host sync per trajectory in the reference)."""
+    quiet = bool(getattr(opt, 'quiet', False))
+    noise = getattr(opt, 'noise_source', None)
+    if noise is None:
+        seed = getattr(opt, 'philox_seed', None)
+        noise = PhiloxNoise(seed, getattr(opt, 'chain_id0', 0)) if seed is not None else TorchNoise()
+
+    def log(it, status, state, out, x_orig_):
+        if quiet or not bool(status[1][0]):
+            return
+        ps = K.psnr(out['xt'][:1].contiguous(), x_orig_[:1].contiguous())
+        print('epoch', int(status[0][0]), 'PSNR:', float(ps[0]), 'sigma_y:', float(state['sigma_y'][0]),
+              'tau:', float(state['tau'][0]))
+        if getattr(opt, 'save_images', False):
+            _save_png(out['xt'][0], os.path.join(opt.image_folder, f'hmc_{int(status[0][0])}.png'))
+
+    res = hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
+                     chunk=getattr(opt, 'score_chunk', None), log=None if quiet else log)
+    return res.samples[0] if n == 1 else res.samples
+
+
+def _save_png(img, path):
+    """inverse_data_transform + 8-bit PNG (the reference uses torchvision.utils.save_image)."""
+    from PIL import Image
+    arr = ((img.detach().clamp(-1, 1) + 1) * 127.5).round().byte().permute(1, 2, 0).cpu().numpy()
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    Image.fromarray(arr).save(path)

@@ -7,9 +7,23 @@ Restates
 and, for the kernels' backward, the closed-form VJP autograd derives from them
 (SURVEY.md section 8 row a11).
 """
+import numpy as np
 import torch
 
 from .schedule import alpha_bar
+
+
+def sqrt_rn(t):
+    """IEEE correctly rounded fp32 square root of a (grad-free) tensor.
+
+    torch's CPU `sqrt` is NOT correctly rounded and depends on the host CPU: against the exact
+    root it is 1 ulp off for 6 of the 1001 alpha-bar table entries in the build container and for
+    183 of them on the GPU box's host (both "AVX512" builds; measured), while numpy's fp32 sqrt,
+    torch's GPU sqrt and the HIP kernels' sqrtf are exact everywhere.  The oracle therefore takes
+    the root with numpy so that it means the same thing on every machine; for the alpha-bars the
+    reference path uses (t = 750/500/250/-1) the container's torch sqrt is exact too, so the
+    fixtures captured from the reference are unaffected (tests/test_oracle_golden.py)."""
+    return torch.from_numpy(np.sqrt(t.detach().numpy()))
 
 
 def predict_x0(xt, et, at, at_next):
@@ -18,15 +32,15 @@ def predict_x0(xt, et, at, at_next):
     Division (not reciprocal multiply) and fp32 sqrt of [n,1,1,1] tensors."""
     if et.size(1) == 6:
         et = et[:, :3]
-    x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+    x0_t = (xt - et * sqrt_rn(1 - at)) / sqrt_rn(at)
     x0_t = x0_t.clip(-1, 1)
-    add_up = (1 - at_next).sqrt() * et
+    add_up = sqrt_rn(1 - at_next) * et
     return x0_t, add_up
 
 
 def renoise(x0_t, add_up, at_next):
     """algos/unconditional.py:26-28."""
-    return at_next.sqrt() * x0_t + add_up
+    return sqrt_rn(at_next) * x0_t + add_up
 
 
 def ddim_step(xt, et, at, at_next):
@@ -60,8 +74,8 @@ def ddim_step_vjp(gout, xt, et, at, at_next):
         d/det = gout c4 - (d/dxt) c1            (zero for channels 3..5)
     """
     e3 = et[:, :3]
-    c1, c2 = (1 - at).sqrt(), at.sqrt()
-    c3, c4 = at_next.sqrt(), (1 - at_next).sqrt()
+    c1, c2 = sqrt_rn(1 - at), sqrt_rn(at)
+    c3, c4 = sqrt_rn(at_next), sqrt_rn(1 - at_next)
     u = (xt - e3 * c1) / c2
     mask = ((u >= -1) & (u <= 1)).to(gout.dtype)
     g_u = (gout * c3) * mask / c2
