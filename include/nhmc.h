@@ -46,6 +46,8 @@ enum {
 #define NHMC_ABI_VERSION 1
 int nhmc_abi_version(void);
 const char* nhmc_status_string(int status);
+/* HIP's message for the last NHMC_ERR_LAUNCH raised on the calling thread (diagnostics only). */
+const char* nhmc_last_launch_error(void);
 
 /* ------------------------------------------------------------------------------------
  * a1-a4  Fused leapfrog update            main_sampling.py:702,706-707,713,715

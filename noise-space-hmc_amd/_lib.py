@@ -15,6 +15,7 @@ P, I, I64, D, F, U32, U64, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_
 SIGNATURES = {
     'nhmc_abi_version': (I, []),
     'nhmc_status_string': (C.c_char_p, [I]),
+    'nhmc_last_launch_error': (C.c_char_p, []),
     'nhmc_leapfrog_tiles': (I, [I64]),
     'nhmc_leapfrog_ws_bytes': (SZ, [I, I64]),
     'nhmc_leapfrog_fused': (I, [I, P, P, P, P, P, P, D, I, I64, P, P]),
@@ -61,6 +62,10 @@ def load():
             f'{LIB_PATH} is missing: the HIP extension has not been built. '
             'Run `python noise-space-hmc_amd/build.py` (or __graft_entry__.build()). '
             'There is no CPU fallback for the sampler kernels.')
+    # torch ships its own libamdhip64 (same soname as /opt/rocm's).  Whichever copy is loaded first serves
+    # the whole process, and libnhmc must launch on the runtime that owns torch's device context and
+    # streams -- so make sure torch's is in before dlopen resolves our NEEDED entry.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
@@ -77,4 +82,6 @@ def load():
 def check(status, what):
     if status != 0:
         msg = load().nhmc_status_string(status).decode()
+        if status == 4:
+            msg += ': ' + load().nhmc_last_launch_error().decode()
         raise NhmcError(f'{what}: {msg} (status {status})')

@@ -207,7 +207,7 @@ int launch_sr(int ratio, const float* xin, const float* y_in, float* y_out, int 
               float* g_out, double* ws, int n_chains, int channels, int dim, hipStream_t st) {
   dim3 grid((unsigned)sr_tiles(channels, dim, ratio), (unsigned)n_chains), block(NHMC_BLOCK);
 #define NHMC_SR(R)                                                                                          \
-  hipLaunchKernelGGL((k_sr<R, MODE>), grid, block, 0, st, (const float4*)xin, y_in, y_out, apply_clip, scale, \
+  NHMC_LAUNCH((k_sr<R, MODE>), grid, block, 0, st, (const float4*)xin, y_in, y_out, apply_clip, scale, \
                      (float4*)g_out, ws, dim, channels)
   switch (ratio) {
     case 2: NHMC_SR(2); break;
@@ -245,7 +245,7 @@ extern "C" int nhmc_data_inpaint(const float* xt, const float* y, const int32_t*
   if (n_chains > 65535) return NHMC_ERR_SHAPE;
   if ((n_elem & 3) || !nhmc_aligned16(xt) || !nhmc_aligned16(slot) || !nhmc_aligned16(g_xt)) return NHMC_ERR_ALIGN;
   dim3 grid((unsigned)nhmc_data_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  hipLaunchKernelGGL(k_data_inpaint, grid, block, 0, nhmc_s(stream), (const float4*)xt, y, (const int4*)slot,
+  NHMC_LAUNCH(k_data_inpaint, grid, block, 0, nhmc_s(stream), (const float4*)xt, y, (const int4*)slot,
                      apply_clip, (float4*)g_xt, loss_ws, n_elem / 4, m);
   return nhmc_launch_status();
 }
@@ -255,7 +255,7 @@ extern "C" int nhmc_inpaint_H(const float* x, const int32_t* kept_chw, float* y,
   if (!x || !kept_chw || !y || n_chains <= 0 || n_elem <= 0 || m <= 0) return NHMC_ERR_ARG;
   if (n_chains > 65535) return NHMC_ERR_SHAPE;
   dim3 grid((unsigned)((m + NHMC_BLOCK - 1) / NHMC_BLOCK), (unsigned)n_chains), block(NHMC_BLOCK);
-  hipLaunchKernelGGL(k_inpaint_H, grid, block, 0, nhmc_s(stream), x, kept_chw, y, n_elem, m);
+  NHMC_LAUNCH(k_inpaint_H, grid, block, 0, nhmc_s(stream), x, kept_chw, y, n_elem, m);
   return nhmc_launch_status();
 }
 
@@ -265,7 +265,7 @@ extern "C" int nhmc_inpaint_Ht(const float* y, const int32_t* slot, float* x, in
   if (n_chains > 65535) return NHMC_ERR_SHAPE;
   if ((n_elem & 3) || !nhmc_aligned16(slot) || !nhmc_aligned16(x)) return NHMC_ERR_ALIGN;
   dim3 grid((unsigned)nhmc_data_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  hipLaunchKernelGGL(k_inpaint_Ht, grid, block, 0, nhmc_s(stream), y, (const int4*)slot, (float4*)x, n_elem / 4, m);
+  NHMC_LAUNCH(k_inpaint_Ht, grid, block, 0, nhmc_s(stream), y, (const int4*)slot, (float4*)x, n_elem / 4, m);
   return nhmc_launch_status();
 }
 
@@ -299,7 +299,7 @@ extern "C" int nhmc_sum_partials(const double* ws, int tiles, int stride, int of
                                  nhmc_stream_t stream) {
   if (!ws || !out || tiles <= 0 || stride <= 0 || offset < 0 || offset >= stride || n_chains <= 0) return NHMC_ERR_ARG;
   const int per = NHMC_BLOCK / NHMC_WAVE;
-  hipLaunchKernelGGL(k_sum_partials, dim3((n_chains + per - 1) / per), dim3(NHMC_BLOCK), 0, nhmc_s(stream), ws,
+  NHMC_LAUNCH(k_sum_partials, dim3((n_chains + per - 1) / per), dim3(NHMC_BLOCK), 0, nhmc_s(stream), ws,
                      tiles, stride, offset, n_chains, out);
   return nhmc_launch_status();
 }

@@ -161,7 +161,7 @@ extern "C" int nhmc_ddim_mix_fwd(const float* xt, const float* e, int e_channels
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
   hipStream_t st = nhmc_s(stream);
 #define NHMC_FWD(A, B, C)                                                                             \
-  hipLaunchKernelGGL((k_mix_fwd<A, B, C>), grid, block, 0, st, (const float4*)xt, (const float4*)e, es4, \
+  NHMC_LAUNCH((k_mix_fwd<A, B, C>), grid, block, 0, st, (const float4*)xt, (const float4*)e, es4, \
                      at, at_next, final_clip, (float4*)xt_next, (float4*)x0_t, (float4*)add_up, n4)
   const int sel = (xt_next ? 4 : 0) | (x0_t ? 2 : 0) | (add_up ? 1 : 0);
   switch (sel) {
@@ -184,7 +184,7 @@ extern "C" int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const 
   if ((n_elem & 3) || !nhmc_aligned16(x0_t) || !nhmc_aligned16(add_up) || !nhmc_aligned16(xt_next))
     return NHMC_ERR_ALIGN;
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  hipLaunchKernelGGL(k_map_back, grid, block, 0, nhmc_s(stream), (const float4*)x0_t, (const float4*)add_up,
+  NHMC_LAUNCH(k_map_back, grid, block, 0, nhmc_s(stream), (const float4*)x0_t, (const float4*)add_up,
                      at_next, (float4*)xt_next, n_elem / 4);
   return nhmc_launch_status();
 }
@@ -204,7 +204,7 @@ extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const fl
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
   hipStream_t st = nhmc_s(stream);
 #define NHMC_BWD(G2, SP)                                                                                  \
-  hipLaunchKernelGGL((k_mix_bwd<G2, SP>), grid, block, 0, st, (const float4*)gout, (const float4*)gout2,     \
+  NHMC_LAUNCH((k_mix_bwd<G2, SP>), grid, block, 0, st, (const float4*)gout, (const float4*)gout2,     \
                      (const float4*)g_x0, (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, \
                      (float4*)g_xt, (float4*)g_e, n4)
   if (g_x0) NHMC_BWD(false, true);

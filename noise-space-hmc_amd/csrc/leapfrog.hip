@@ -90,10 +90,10 @@ int launch(float* x, float* p, const float* g, const float* g2, const double* ep
   const int64_t n4 = n_elem / 4;
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
   if (g2)
-    hipLaunchKernelGGL((k_leapfrog<MODE, true>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
+    NHMC_LAUNCH((k_leapfrog<MODE, true>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
                        (const float4*)g2, eps, sigma_y, m_inv, n4, ws);
   else
-    hipLaunchKernelGGL((k_leapfrog<MODE, false>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
+    NHMC_LAUNCH((k_leapfrog<MODE, false>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
                        (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws);
   return nhmc_launch_status();
 }

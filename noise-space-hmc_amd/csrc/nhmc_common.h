@@ -11,7 +11,17 @@
 
 static inline bool nhmc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline hipStream_t nhmc_s(nhmc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
-static inline int nhmc_launch_status() { return hipGetLastError() == hipSuccess ? NHMC_OK : NHMC_ERR_LAUNCH; }
+inline thread_local hipError_t nhmc_last_hip_error = hipSuccess;   // last launch error of this thread (diagnostics)
+static inline int nhmc_launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return NHMC_OK;
+  nhmc_last_hip_error = e;
+  return NHMC_ERR_LAUNCH;
+}
+// hipGetLastError() is per-thread and sticky: the host framework around us leaves benign codes behind
+// (e.g. hipErrorNotReady from event polling).  Clear it right before every launch so that
+// nhmc_launch_status() reports this launch only.
+#define NHMC_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 // Wave-level sum over 64 lanes with shuffles; result valid in lane 0.
 __device__ __forceinline__ double nhmc_wave_sum(double v) {

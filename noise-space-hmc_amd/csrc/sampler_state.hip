@@ -208,6 +208,8 @@ inline dim3 wave_grid(int n) { return dim3((unsigned)((n + 3) / 4)); }
 
 extern "C" int nhmc_abi_version(void) { return NHMC_ABI_VERSION; }
 
+extern "C" const char* nhmc_last_launch_error(void) { return hipGetErrorString(nhmc_last_hip_error); }
+
 extern "C" const char* nhmc_status_string(int status) {
   switch (status) {
     case NHMC_OK: return "ok";
@@ -222,7 +224,7 @@ extern "C" const char* nhmc_status_string(int status) {
 extern "C" int nhmc_hamiltonian(const double* sums_ws, int tiles, const double* loss, const double* sigma_y,
                                 double m_inv, float* H_out, double* terms, int n_chains, nhmc_stream_t stream) {
   if (!sums_ws || !loss || !sigma_y || !H_out || tiles <= 0 || n_chains <= 0) return NHMC_ERR_ARG;
-  hipLaunchKernelGGL(k_hamiltonian, wave_grid(n_chains), dim3(256), 0, nhmc_s(stream), sums_ws, tiles, loss, sigma_y,
+  NHMC_LAUNCH(k_hamiltonian, wave_grid(n_chains), dim3(256), 0, nhmc_s(stream), sums_ws, tiles, loss, sigma_y,
                      m_inv, H_out, terms, n_chains);
   return nhmc_launch_status();
 }
@@ -230,7 +232,7 @@ extern "C" int nhmc_hamiltonian(const double* sums_ws, int tiles, const double* 
 extern "C" int nhmc_metropolis(const float* H0, const float* H1, const float* u, const int32_t* active,
                                int32_t* accept, float* dH, int n_chains, nhmc_stream_t stream) {
   if (!H0 || !H1 || !u || !accept || n_chains <= 0) return NHMC_ERR_ARG;
-  hipLaunchKernelGGL(k_metropolis, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), H0, H1, u, active, accept, dH,
+  NHMC_LAUNCH(k_metropolis, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), H0, H1, u, active, accept, dH,
                      n_chains);
   return nhmc_launch_status();
 }
@@ -240,7 +242,7 @@ extern "C" int nhmc_schedule_begin(const int32_t* epoch, double* tau, double* ep
                                    nhmc_stream_t stream) {
   if (!epoch || !tau || !eps || !sigma_y || !eps_eff || !active || epochs <= 0 || sampling < 0 || n_chains <= 0)
     return NHMC_ERR_ARG;
-  hipLaunchKernelGGL(k_schedule_begin, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), epoch, tau, eps, sigma_y,
+  NHMC_LAUNCH(k_schedule_begin, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), epoch, tau, eps, sigma_y,
                      eps_eff, active, sigma_0, epochs, sampling, n_chains);
   return nhmc_launch_status();
 }
@@ -249,7 +251,7 @@ extern "C" int nhmc_schedule_end(const int32_t* accept, const int32_t* active, i
                                  double* tau, double* eps, int32_t* n_accept, int32_t* n_reject, int n_chains,
                                  nhmc_stream_t stream) {
   if (!accept || !active || !epoch || !rejected || !tau || !eps || n_chains <= 0) return NHMC_ERR_ARG;
-  hipLaunchKernelGGL(k_schedule_end, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), accept, active, epoch,
+  NHMC_LAUNCH(k_schedule_end, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), accept, active, epoch,
                      rejected, tau, eps, n_accept, n_reject, n_chains);
   return nhmc_launch_status();
 }
@@ -264,7 +266,7 @@ extern "C" int nhmc_accept_commit(const int32_t* accept, const int32_t* epoch, f
       !nhmc_aligned16(samples))
     return NHMC_ERR_ALIGN;
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  hipLaunchKernelGGL(k_accept_commit, grid, block, 0, nhmc_s(stream), accept, epoch, (float4*)x,
+  NHMC_LAUNCH(k_accept_commit, grid, block, 0, nhmc_s(stream), accept, epoch, (float4*)x,
                      (const float4*)x_prop, (const float4*)xt_prop, (float4*)samples, epochs, sampling, n_elem / 4);
   return nhmc_launch_status();
 }
@@ -275,9 +277,9 @@ extern "C" int nhmc_psnr(const float* xt, const float* x_orig, float* psnr, doub
   if (n_chains > 65535) return NHMC_ERR_SHAPE;
   if ((n_elem & 3) || !nhmc_aligned16(xt) || !nhmc_aligned16(x_orig)) return NHMC_ERR_ALIGN;
   const int tiles = nhmc_data_tiles(n_elem);
-  hipLaunchKernelGGL(k_psnr_partial, dim3((unsigned)tiles, (unsigned)n_chains), dim3(NHMC_BLOCK), 0, nhmc_s(stream),
+  NHMC_LAUNCH(k_psnr_partial, dim3((unsigned)tiles, (unsigned)n_chains), dim3(NHMC_BLOCK), 0, nhmc_s(stream),
                      (const float4*)xt, (const float4*)x_orig, ws, n_elem / 4);
-  hipLaunchKernelGGL(k_psnr_final, wave_grid(n_chains), dim3(256), 0, nhmc_s(stream), ws, tiles, n_elem, psnr,
+  NHMC_LAUNCH(k_psnr_final, wave_grid(n_chains), dim3(256), 0, nhmc_s(stream), ws, tiles, n_elem, psnr,
                      n_chains);
   return nhmc_launch_status();
 }
@@ -288,7 +290,7 @@ extern "C" int nhmc_randn_philox(float* out, uint64_t seed, uint32_t chain_id0, 
   if (n_chains > 65535) return NHMC_ERR_SHAPE;
   if ((n_elem & 3) || !nhmc_aligned16(out)) return NHMC_ERR_ALIGN;
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  hipLaunchKernelGGL(k_randn, grid, block, 0, nhmc_s(stream), (float4*)out, (uint32_t)(seed & 0xffffffffu),
+  NHMC_LAUNCH(k_randn, grid, block, 0, nhmc_s(stream), (float4*)out, (uint32_t)(seed & 0xffffffffu),
                      (uint32_t)(seed >> 32), chain_id0, draw, scale, n_elem / 4);
   return nhmc_launch_status();
 }
@@ -296,7 +298,7 @@ extern "C" int nhmc_randn_philox(float* out, uint64_t seed, uint32_t chain_id0, 
 extern "C" int nhmc_uniform_philox(float* out, uint64_t seed, uint32_t chain_id0, uint32_t draw, int n_chains,
                                    nhmc_stream_t stream) {
   if (!out || n_chains <= 0) return NHMC_ERR_ARG;
-  hipLaunchKernelGGL(k_uniform, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), out, (uint32_t)(seed & 0xffffffffu),
+  NHMC_LAUNCH(k_uniform, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), out, (uint32_t)(seed & 0xffffffffu),
                      (uint32_t)(seed >> 32), chain_id0, draw, n_chains);
   return nhmc_launch_status();
 }

@@ -144,13 +144,13 @@ int gemm(const float* X, const float* S, float* Cout, const float* Dmap, const f
          int channels, int d, hipStream_t st) {
   if (d % 128 == 0) {
     dim3 grid(d / 128, d / 128, n_img);
-    hipLaunchKernelGGL((k_sgemm<128, 2, LEFT, EPI, PRECLIP>), grid, dim3(256), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
+    NHMC_LAUNCH((k_sgemm<128, 2, LEFT, EPI, PRECLIP>), grid, dim3(256), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
   } else if (d % 64 == 0) {
     dim3 grid(d / 64, d / 64, n_img);
-    hipLaunchKernelGGL((k_sgemm<64, 2, LEFT, EPI, PRECLIP>), grid, dim3(256), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
+    NHMC_LAUNCH((k_sgemm<64, 2, LEFT, EPI, PRECLIP>), grid, dim3(256), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
   } else {
     dim3 grid(d / 32, d / 32, n_img);
-    hipLaunchKernelGGL((k_sgemm<32, 1, LEFT, EPI, PRECLIP>), grid, dim3(64), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
+    NHMC_LAUNCH((k_sgemm<32, 1, LEFT, EPI, PRECLIP>), grid, dim3(64), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
   }
   return nhmc_launch_status();
 }

@@ -1,0 +1,164 @@
+"""Score network for the FFHQ config: an ADM-style U-Net in plain PyTorch-ROCm.
+
+Out of scope as a kernel target (north_star keeps the score evaluations on PyTorch-ROCm; SURVEY.md
+section 8 row a16) but needed to run and measure the hot path end to end.  The module tree and
+parameter names follow guided_diffusion's checkpoint layout (`time_embed.0`, `input_blocks.k.0.in_layers.0`,
+`...emb_layers.1`, `...out_layers.3`, `...skip_connection`, `k.1.norm/qkv/proj_out`, `middle_block`,
+`output_blocks`, `out.0/out.2`) so that `models/ffhq_10m.pt` loads with `load_state_dict` unchanged
+(reference: guided_diffusion/unet_ffhq.py:25-91 `create_model`, :467-734 `UNetModel`; config
+configs/config_ffhq.yml:17-35).  When the checkpoint is absent the weights stay randomly initialised,
+as in the reference's own fallback (unet_ffhq.py:87-90).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+FFHQ_CONFIG = dict(image_size=256, num_channels=128, num_res_blocks=1, channel_mult='', learn_sigma=True,
+                   attention_resolutions='16', num_head_channels=64, use_scale_shift_norm=True,
+                   resblock_updown=True)
+_DEFAULT_MULT = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+
+
+def sinusoid(t, dim, max_period=10000):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
+    ang = t[:, None].float() * freqs[None]
+    emb = torch.cat([ang.cos(), ang.sin()], dim=-1)
+    return F.pad(emb, (0, dim % 2))
+
+
+class Resample(nn.Module):
+    """Parameter-free 2x nearest upsample / 2x2 average pool (the reference's conv-less up/down)."""
+
+    def __init__(self, up):
+        super().__init__()
+        self.up = up
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode='nearest') if self.up else F.avg_pool2d(x, 2)
+
+
+class ResBlock(nn.Module):
+    takes_emb = True
+
+    def __init__(self, ch, emb_ch, out_ch=None, up=False, down=False):
+        super().__init__()
+        out_ch = out_ch or ch
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(ch, out_ch, 3, padding=1))
+        self.resample = up or down
+        self.h_upd = self.x_upd = Resample(up) if self.resample else nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_ch, 2 * out_ch))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, out_ch), nn.SiLU(), nn.Identity(),
+                                        nn.Conv2d(out_ch, out_ch, 3, padding=1))
+        self.skip_connection = nn.Identity() if out_ch == ch else nn.Conv2d(ch, out_ch, 1)
+
+    def forward(self, x, emb):
+        if self.resample:
+            h = self.in_layers[1](self.in_layers[0](x))
+            h, x = self.h_upd(h), self.x_upd(x)
+            h = self.in_layers[2](h)
+        else:
+            h = self.in_layers(x)
+        scale, shift = self.emb_layers(emb)[:, :, None, None].chunk(2, dim=1)
+        h = self.out_layers[0](h) * (1 + scale) + shift                  # scale-shift norm (FiLM)
+        h = self.out_layers[3](self.out_layers[1](h))
+        return self.skip_connection(x) + h
+
+
+class AttentionBlock(nn.Module):
+    takes_emb = False
+
+    def __init__(self, ch, head_ch):
+        super().__init__()
+        self.heads = ch // head_ch
+        self.norm = nn.GroupNorm(32, ch)
+        self.qkv = nn.Conv1d(ch, 3 * ch, 1)
+        self.proj_out = nn.Conv1d(ch, ch, 1)
+
+    def forward(self, x):
+        b, c, hh, ww = x.shape
+        x = x.reshape(b, c, -1)
+        qkv = self.qkv(self.norm(x))
+        # "legacy" order: heads are split before q/k/v
+        q, k, v = qkv.reshape(b * self.heads, 3 * c // self.heads, -1).split(c // self.heads, dim=1)
+        s = 1 / math.sqrt(math.sqrt(c // self.heads))
+        w = torch.softmax(torch.einsum('bct,bcs->bts', q * s, k * s), dim=-1)
+        h = torch.einsum('bts,bcs->bct', w, v).reshape(b, c, -1)
+        return (x + self.proj_out(h)).reshape(b, c, hh, ww)
+
+
+class Stage(nn.Sequential):
+    def forward(self, x, emb):
+        for layer in self:
+            x = layer(x, emb) if getattr(layer, 'takes_emb', False) else layer(x)
+        return x
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size=256, in_channels=3, model_channels=128, out_channels=6, num_res_blocks=1,
+                 attention_ds=(16,), channel_mult=(1, 1, 2, 2, 4, 4), num_head_channels=64):
+        super().__init__()
+        self.model_channels = mc = model_channels
+        emb = 4 * mc
+        self.time_embed = nn.Sequential(nn.Linear(mc, emb), nn.SiLU(), nn.Linear(emb, emb))
+        ch = int(channel_mult[0] * mc)
+        self.input_blocks = nn.ModuleList([Stage(nn.Conv2d(in_channels, ch, 3, padding=1))])
+        skip_chs, ds = [ch], 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, emb, int(mult * mc))]
+                ch = int(mult * mc)
+                if ds in attention_ds:
+                    layers.append(AttentionBlock(ch, num_head_channels))
+                self.input_blocks.append(Stage(*layers))
+                skip_chs.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(Stage(ResBlock(ch, emb, ch, down=True)))
+                skip_chs.append(ch)
+                ds *= 2
+        self.middle_block = Stage(ResBlock(ch, emb), AttentionBlock(ch, num_head_channels), ResBlock(ch, emb))
+        self.output_blocks = nn.ModuleList()
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + skip_chs.pop(), emb, int(mc * mult))]
+                ch = int(mc * mult)
+                if ds in attention_ds:
+                    layers.append(AttentionBlock(ch, num_head_channels))
+                if level and i == num_res_blocks:
+                    layers.append(ResBlock(ch, emb, ch, up=True))
+                    ds //= 2
+                self.output_blocks.append(Stage(*layers))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(ch, out_channels, 3, padding=1))
+
+    def forward(self, x, timesteps, y=None):
+        emb = self.time_embed(sinusoid(timesteps, self.model_channels))
+        hs, h = [], x
+        for blk in self.input_blocks:
+            h = blk(h, emb)
+            hs.append(h)
+        h = self.middle_block(h, emb)
+        for blk in self.output_blocks:
+            h = blk(torch.cat([h, hs.pop()], dim=1), emb)
+        return self.out(h)
+
+
+def create_model(image_size=256, num_channels=128, num_res_blocks=1, channel_mult='', learn_sigma=True,
+                 class_cond=False, use_checkpoint=False, attention_resolutions='16', num_heads=4,
+                 num_head_channels=64, num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0,
+                 resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path=''):
+    """Keyword-compatible with the reference factory (unet_ffhq.py:25-91) for the options the FFHQ
+    config uses; anything that would change the architecture away from it is rejected loudly."""
+    if class_cond or use_fp16 or use_new_attention_order or not use_scale_shift_norm or not resblock_updown \
+            or num_head_channels <= 0 or dropout:
+        raise NotImplementedError('only the FFHQ-config architecture variant is built here')
+    mult = _DEFAULT_MULT[image_size] if channel_mult == '' else tuple(int(c) for c in str(channel_mult).split(','))
+    att = tuple(image_size // int(r) for r in str(attention_resolutions).split(','))
+    model = UNetModel(image_size, 3, num_channels, 6 if learn_sigma else 3, num_res_blocks, att, mult, num_head_channels)
+    import os
+    if model_path and os.path.exists(model_path):
+        model.load_state_dict(torch.load(model_path, map_location='cpu', weights_only=True))
+    elif model_path:
+        print(f'checkpoint {model_path} not found / randomly initialised')
+    return model

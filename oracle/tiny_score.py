@@ -22,7 +22,7 @@ class TinyScore(nn.Module):
         self.out = nn.Conv2d(width, out_ch, 3, padding=1)
 
     def forward(self, x, t):
-        ph = t.float()[:, None] * torch.tensor([1.0, 2.0, 3.0, 5.0], device=x.device) * (math.pi / 1000.0)
+        ph = t.to(x.dtype)[:, None] * torch.tensor([1.0, 2.0, 3.0, 5.0], device=x.device, dtype=x.dtype) * (math.pi / 1000.0)
         emb = self.temb(torch.cat([ph.sin()[:, :2], ph.cos()[:, 2:]], dim=1))
         h = torch.tanh(self.inp(x) + emb[:, :, None, None])
         h = torch.tanh(self.mid(h)) + h

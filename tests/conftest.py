@@ -10,7 +10,20 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+def _host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(min(16, _host_cores()))       # the GPU box shows 256 CPUs but grants 16
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
