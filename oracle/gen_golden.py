@@ -264,3 +264,35 @@ if __name__ == '__main__':
             g4_hmc(ms, deg)
     if 'g5' in which:
         g5_ops_256(ms)
+
+
+def g6_unet(ms):
+    """Reference U-Net architecture (guided_diffusion/unet_ffhq.py) at a reduced width with seeded weights:
+    pins nhmc.unet's module tree (state_dict keys, in order) and forward arithmetic."""
+    from guided_diffusion.unet_ffhq import create_model
+    import hashlib
+    cfg = dict(image_size=64, num_channels=32, num_res_blocks=1, channel_mult='', learn_sigma=True, class_cond=False,
+               use_checkpoint=False, attention_resolutions='16', num_heads=4, num_head_channels=16,
+               num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0, resblock_updown=True, use_fp16=False,
+               use_new_attention_order=False, model_path='')
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = create_model(**cfg).eval()
+    g = torch.Generator().manual_seed(606)
+    sd = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    t = torch.tensor([750.0, 250.0])
+    with torch.no_grad():
+        out = net(x, t)
+    with contextlib.redirect_stdout(io.StringIO()):
+        full = create_model(**{**cfg, 'image_size': 256, 'num_channels': 128, 'num_head_channels': 64})
+    keys_small = '\n'.join(f'{k} {tuple(v.shape)}' for k, v in net.state_dict().items())
+    keys_full = '\n'.join(f'{k} {tuple(v.shape)}' for k, v in full.state_dict().items())
+    save('g6_unet_64.npz', x=np32(x), t=np32(t), out=np32(out), weight_seed=np.array(606), weight_scale=np.array(0.05),
+         keys_small_sha256=np.array(hashlib.sha256(keys_small.encode()).hexdigest()),
+         keys_ffhq_sha256=np.array(hashlib.sha256(keys_full.encode()).hexdigest()),
+         n_params_ffhq=np.array(sum(v.numel() for v in full.state_dict().values())))
+
+
+if __name__ == '__main__' and 'g6' in (sys.argv[1:] or ['g6']):
+    g6_unet(import_reference() if 'main_sampling' not in sys.modules else sys.modules['main_sampling'])

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof_rNN/...) into the small files kept under profiles/.
+
+    python profiles/summarize.py gpurun_out/prof_r01 r01
+
+Writes profiles/<tag>_kernel_stats_hip.csv   (our HIP kernels, from the --kernel-only run)
+       profiles/<tag>_kernel_stats_e2e_top.csv (top 40 kernels of the end-to-end run)
+       profiles/<tag>_pmc_hbm.csv            (per-kernel mean FETCH_SIZE / WRITE_SIZE per launch)
+       profiles/traffic_leapfrog.json        (HBM bytes per launch of the dominant kernel; read by bench.py)
+Counter handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
+separate passes, are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced
+streaming read, so it is doubled for our 16-B-per-lane kernels.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+OURS = ('k_leapfrog', 'k_mix_', 'k_map_back', 'k_data_inpaint', 'k_inpaint', 'k_sr', 'k_sgemm', 'k_sum_partials',
+        'k_hamiltonian', 'k_metropolis', 'k_schedule', 'k_accept_commit', 'k_psnr', 'k_randn', 'k_uniform')
+
+
+def short(name):
+    n = name.replace('void ', '').replace('(anonymous namespace)::', '')
+    return n.split('(')[0]
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(src, pattern))
+    return hits[0] if hits else None
+
+
+def stats(path, out, keep):
+    rows = list(csv.DictReader(open(path)))
+    with open(out, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
+        for r in rows:
+            if keep(r):
+                w.writerow([short(r['Name'])[:110], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'],
+                            r['MinNs'], r['MaxNs'], r['StdDev']])
+
+
+p = one('kern/*/*_kernel_stats.csv')
+if p:
+    stats(p, os.path.join(here, f'{tag}_kernel_stats_hip.csv'), lambda r: any(k in r['Name'] for k in OURS))
+p = one('e2e/*/*_kernel_stats.csv')
+if p:
+    rows = list(csv.DictReader(open(p)))
+    top = set(r['Name'] for r in rows[:40])
+    stats(p, os.path.join(here, f'{tag}_kernel_stats_e2e_top.csv'), lambda r: r['Name'] in top or any(k in r['Name'] for k in OURS))
+
+acc = defaultdict(lambda: defaultdict(list))
+for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
+    p = one(f'{sub}/*/*_counter_collection.csv')
+    if not p:
+        continue
+    for r in csv.DictReader(open(p)):
+        if r['Counter_Name'] == counter and any(k in r['Kernel_Name'] for k in OURS):
+            acc[short(r['Kernel_Name'])][counter].append(float(r['Counter_Value']))
+if acc:
+    with open(os.path.join(here, f'{tag}_pmc_hbm.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'launches', 'FETCH_SIZE_KiB_mean', 'WRITE_SIZE_KiB_mean', 'hbm_bytes_per_launch(2*FETCH+WRITE)'])
+        for k, d in sorted(acc.items()):
+            fe = sum(d['FETCH_SIZE']) / max(1, len(d['FETCH_SIZE']))
+            wr = sum(d['WRITE_SIZE']) / max(1, len(d['WRITE_SIZE']))
+            w.writerow([k[:110], len(d['FETCH_SIZE']), f'{fe:.1f}', f'{wr:.1f}', f'{(2 * fe + wr) * 1024:.0f}'])
+            if k.startswith('k_leapfrog<1, false>'):
+                json.dump({'kernel': k, 'fetch_size_kib': fe, 'write_size_kib': wr,
+                           'hbm_bytes_per_launch': (2 * fe + wr) * 1024,
+                           'note': 'FETCH_SIZE doubled (gfx950 wide-read correction), separate --pmc passes, source ' + tag},
+                          open(os.path.join(here, 'traffic_leapfrog.json'), 'w'), indent=1)
+print('ok')
