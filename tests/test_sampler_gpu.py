@@ -210,3 +210,26 @@ def test_reference_entry_point_shapes_and_shard_invariance():
     out = sampler.hmc(x[:1], 1, b, SEQ, SEQ_NEXT, algo, opt1, y[:1], op, x_orig[:1])
     assert out.shape == (20, 3, dim, dim) and bool(torch.isfinite(out).all())
     assert float(out.abs().max()) <= 1.0
+
+
+def test_cli_runs_the_reference_command_line(tmp_path, monkeypatch, capsys):
+    """`main_sampling.py`-compatible flags end to end on a small config (32x32 U-Net of the same architecture)."""
+    import yaml
+    from nhmc import cli
+    cfgdir = tmp_path / 'configs'
+    cfgdir.mkdir()
+    cfg = {'data': {'dataset': 'tiny', 'image_size': 32, 'channels': 3, 'rescaled': True},
+           'model': dict(image_size=32, num_channels=32, num_res_blocks=1, channel_mult='1,2', learn_sigma=True,
+                         class_cond=False, use_checkpoint=False, attention_resolutions='16', num_heads=4,
+                         num_head_channels=16, num_heads_upsample=-1, use_scale_shift_norm=True, dropout=0.0,
+                         resblock_updown=True, use_fp16=False, use_new_attention_order=False, model_path=''),
+           'diffusion': {'beta_schedule': 'linear', 'beta_start': 1e-4, 'beta_end': 0.02, 'num_diffusion_timesteps': 1000}}
+    (cfgdir / 'config_tiny.yml').write_text(yaml.safe_dump(cfg))
+    monkeypatch.chdir(tmp_path)
+    table = cli.main(['--dataset', 'tiny', '--algo', 'hmc', '--timesteps', '3', '--deg', 'sr4', '--sigma_0', '0.05',
+                      '-i', str(tmp_path / 'out'), '--tau', '0.1', '--epsilon', '0.05', '--synthetic', '2', '--chains', '2',
+                      '--philox', '--ni', '--doc', 'ignored'])
+    assert table.shape == (2, 3) and bool(torch.isfinite(table).all())
+    assert 'Total Average PSNR' in capsys.readouterr().out
+    with pytest.raises(NotImplementedError):
+        cli.main(['--dataset', 'tiny', '--algo', 'dps', '--deg', 'sr4', '--sigma_0', '0.05'])
