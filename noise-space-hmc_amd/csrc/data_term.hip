@@ -32,7 +32,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_data_inpaint(
 #pragma unroll
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
-    if (q < n4) { sv[i] = slot[q]; xv[i] = xt[base + q]; }
+    if (q < n4) { sv[i] = slot[q]; xv[i] = nhmc_ldnt(&xt[base + q]); }
   }
 #pragma unroll
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_data_inpaint(
       }
       oe[c] = gr;
     }
-    g_xt[base + q] = o;
+    nhmc_stnt(&g_xt[base + q], o);
   }
   __shared__ double red[4];
   double v[1] = {(double)acc};
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_inpaint_Ht(
     o.y = s.y >= 0 ? yb[s.y] : 0.0f;
     o.z = s.z >= 0 ? yb[s.z] : 0.0f;
     o.w = s.w >= 0 ? yb[s.w] : 0.0f;
-    x[(int64_t)chain * n4 + q] = o;
+    nhmc_stnt(&x[(int64_t)chain * n4 + q], o);
   }
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_sr(
 #pragma unroll
       for (int c = 0; c < 4; ++c) oe[c] = yplane_in[(int64_t)i * yd + (s * 4 + c) / R] * scale;
 #pragma unroll 4
-      for (int rr = 0; rr < R; ++rr) g_out[row0 + (int64_t)rr * w4] = o;
+      for (int rr = 0; rr < R; ++rr) nhmc_stnt(&g_out[row0 + (int64_t)rr * w4], o);
     }
     return;
   }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_sr(
   for (int b = 0; b < BPS; ++b) bs[b] = 0.0f;
   if (live) {
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) rows[rr] = xt[row0 + (int64_t)rr * w4];
+    for (int rr = 0; rr < R; ++rr) rows[rr] = nhmc_ldnt(&xt[row0 + (int64_t)rr * w4]);
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       const float* e = reinterpret_cast<const float*>(&rows[rr]);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_sr(
           if (apply_clip) gr = gr * nhmc_in1(e[c]);
           oe[c] = gr;
         }
-        g_out[row0 + (int64_t)rr * w4] = o;
+        nhmc_stnt(&g_out[row0 + (int64_t)rr * w4], o);
       }
     }
     __shared__ double red[4];

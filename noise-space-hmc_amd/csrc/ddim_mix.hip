@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_fwd(
 #pragma unroll
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
-    if (q < n4) { xv[i] = xt[base + q]; ev[i] = e[ebase + q]; }
+    if (q < n4) { xv[i] = nhmc_ldnt(&xt[base + q]); ev[i] = nhmc_ldnt(&e[ebase + q]); }
   }
 #pragma unroll
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_fwd(
       if (final_clip) nx = nhmc_clip1(nx);
       on[c] = nx; o0[c] = x0; oa[c] = add;
     }
-    if (W_NEXT) xt_next[base + q] = o_next;
-    if (W_X0) x0_t[base + q] = o_x0;
-    if (W_ADD) add_up[base + q] = o_add;
+    if (W_NEXT) nhmc_stnt(&xt_next[base + q], o_next);
+    if (W_X0) nhmc_stnt(&x0_t[base + q], o_x0);
+    if (W_ADD) nhmc_stnt(&add_up[base + q], o_add);
   }
 }
 
@@ -73,10 +73,10 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_map_back(
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     if (q >= n4) continue;
-    const float4 a = x0_t[base + q], b = add_up[base + q];
+    const float4 a = nhmc_ldnt(&x0_t[base + q]), b = nhmc_ldnt(&add_up[base + q]);
     float4 o;
     o.x = c3 * a.x + b.x; o.y = c3 * a.y + b.y; o.z = c3 * a.z + b.z; o.w = c3 * a.w + b.w;
-    xt_next[base + q] = o;
+    nhmc_stnt(&xt_next[base + q], o);
   }
 }
 
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     if (q < n4) {
-      gv[i] = gout[base + q]; xv[i] = xt[base + q]; ev[i] = e[ebase + q];
-      if (SPLIT) sv[i] = g_x0[base + q];
+      gv[i] = nhmc_ldnt(&gout[base + q]); xv[i] = nhmc_ldnt(&xt[base + q]); ev[i] = nhmc_ldnt(&e[ebase + q]);
+      if (SPLIT) sv[i] = nhmc_ldnt(&g_x0[base + q]);
       if (HAS_G2) {
-        const float4 h = gout2[base + q];
+        const float4 h = nhmc_ldnt(&gout2[base + q]);
         gv[i].x += h.x; gv[i].y += h.y; gv[i].z += h.z; gv[i].w += h.w;
       }
     }
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
       gx[c] = gu;
       gee[c] = k.c4 * gin + (-gu) * k.c1;
     }
-    g_xt[base + q] = ox;
-    g_e[ebase + q] = oe;
+    nhmc_stnt(&g_xt[base + q], ox);
+    nhmc_stnt(&g_e[ebase + q], oe);
   }
   // learned-sigma channels of the score gradient are zero (the forward slices them away)
   const int64_t extra = e_stride4 - n4;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
 #pragma unroll
     for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
       const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
-      if (q < extra) g_e[ebase + n4 + q] = z;
+      if (q < extra) nhmc_stnt(&g_e[ebase + n4 + q], z);
     }
   }
 }

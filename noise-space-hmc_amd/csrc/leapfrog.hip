@@ -3,7 +3,7 @@
 // :715 (last half-step undo) and produces the per-chain sums the Hamiltonians at :697/:717 need.
 //
 // HBM-bound streaming kernel: MID reads x,p,g and writes x,p = 20 B/element (5T per chain).
-// grid = (tiles, chains); 256 threads; every thread owns 4 float4 per stream, strided by the
+// grid = (tiles, chains); 256 threads; every thread owns 2 float4 per stream (non-temporal), strided by the
 // block so each wave-instruction touches 1 KiB contiguous.  Per-chain scalars are fp64 device
 // values rounded once to fp32, exactly as `python_float * tensor` does in the reference.
 // Compiled with -ffp-contract=off: mul/add stay separate, matching the reference's ATen op order.
@@ -33,11 +33,11 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     ok[i] = q < n4;
     if (ok[i]) {
-      xv[i] = x[base + q];
-      pv[i] = p[base + q];
-      gv[i] = g[base + q];
+      xv[i] = nhmc_ldnt(&x[base + q]);
+      pv[i] = nhmc_ldnt(&p[base + q]);
+      gv[i] = nhmc_ldnt(&g[base + q]);
       if (HAS_G2) {
-        const float4 h = g2[base + q];
+        const float4 h = nhmc_ldnt(&g2[base + q]);
         gv[i].x += h.x; gv[i].y += h.y; gv[i].z += h.z; gv[i].w += h.w;
       }
     }
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
       }
     }
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
-    p[base + q] = pv[i];
-    if (MODE != NHMC_LF_LAST) x[base + q] = xv[i];
+    nhmc_stnt(&p[base + q], pv[i]);
+    if (MODE != NHMC_LF_LAST) nhmc_stnt(&x[base + q], xv[i]);
   }
 
   if (MODE != NHMC_LF_MID) {

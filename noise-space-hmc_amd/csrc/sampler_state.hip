@@ -104,8 +104,8 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_accept_commit(
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     if (q >= n4) continue;
-    x[base + q] = x_prop[base + q];
-    if (keep) samples[sbase + q] = xt_prop[base + q];
+    nhmc_stnt(&x[base + q], nhmc_ldnt(&x_prop[base + q]));
+    if (keep) nhmc_stnt(&samples[sbase + q], nhmc_ldnt(&xt_prop[base + q]));
   }
 }
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_psnr_partial(const float4* __res
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     if (q >= n4) continue;
-    const float4 a = xt[base + q], b = xo[base + q];
+    const float4 a = nhmc_ldnt(&xt[base + q]), b = nhmc_ldnt(&xo[base + q]);
     const float* ae = reinterpret_cast<const float*>(&a);
     const float* be = reinterpret_cast<const float*>(&b);
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_randn(float4* __restrict__ out, 
     float4 o;
     o.x = (ra * cosf(aa)) * scale; o.y = (ra * sinf(aa)) * scale;
     o.z = (rb * cosf(ab)) * scale; o.w = (rb * sinf(ab)) * scale;
-    out[(int64_t)chain * n4 + q] = o;
+    nhmc_stnt(&out[(int64_t)chain * n4 + q], o);
   }
 }
 

@@ -42,10 +42,10 @@ def test_host_only_entry_points(lib):
     assert lib.nhmc_abi_version() == 1
     assert lib.nhmc_status_string(0) == b'ok' and b'aligned' in lib.nhmc_status_string(2)
     n = 3 * 256 * 256
-    assert lib.nhmc_leapfrog_tiles(n) == 48 and lib.nhmc_leapfrog_tiles(3 * 16 * 16) == 1
-    assert lib.nhmc_leapfrog_ws_bytes(64, n) == 64 * 48 * 2 * 8
-    assert lib.nhmc_data_tiles(n) == 48 and lib.nhmc_sr_tiles(3, 256, 4) == 48 and lib.nhmc_spectral_tiles(3, 256) == 12
-    assert lib.nhmc_data_ws_bytes(2, n) >= 2 * 48 * 8
+    assert lib.nhmc_leapfrog_tiles(n) == 96 and lib.nhmc_leapfrog_tiles(3 * 16 * 16) == 1
+    assert lib.nhmc_leapfrog_ws_bytes(64, n) == 64 * 96 * 2 * 8
+    assert lib.nhmc_data_tiles(n) == 96 and lib.nhmc_sr_tiles(3, 256, 4) == 48 and lib.nhmc_spectral_tiles(3, 256) == 12
+    assert lib.nhmc_data_ws_bytes(2, n) >= 2 * 96 * 8
 
 
 def test_argument_validation_happens_before_any_launch(lib):
