@@ -8,15 +8,18 @@
 // 1e-4 relative parity rules out bf16, and gfx950 has no xf32, so the products run on
 // v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 64 FLOP/clk/SIMD).
 //
-// One kernel, C_img = A * B per d x d image, with one operand the shared factor and the other the image:
-//   LEFT  : C = S^T-layout * X     A(i,k) = S[k][i]   B(k,j) = X[k][j]
-//   RIGHT : C = X * S              A(i,k) = X[i][k]   B(k,j) = S[k][j]
-// (so "multiply by M from the left" passes M^T's memory, "by M from the right" passes M's memory; the host
-// keeps both orientations of the four factors resident -- 2 MB).
-// Block tile T x T (T = 128: 4 waves as 2x2, each 2x2 MFMA tiles; 64: 4 waves, 1 tile each; 32: one wave),
-// K step 32 staged through LDS: k-major tiles so every fragment read is 32 consecutive floats per half-wave
-// (conflict-free ds_read_b32); the RIGHT form's image tile is kept row-major with a +1 pad instead.
-// Epilogues fuse the spectral multiplier, the residual + per-tile loss partial, and the -2 * mask scaling.
+// ONE kernel form serves all eight products of a data-term evaluation:
+//         OUT = IN^T * S          OUT[r][c] = sum_k IN[k][r] * S[k][c]
+// Both operands are k-major in memory (r resp. c contiguous), so global->LDS staging is a straight
+// 16-byte copy and every MFMA fragment read is 32 consecutive floats per half-wave (conflict-free
+// ds_read_b32), with no transposing store and no padding.  Chaining it four times gives the sandwich:
+//     X1 = X^T V1,   X2 = (X1^T V2) o D = (V1^T X V2) o D,   X3 = X2^T U1^T,   X4 = X3^T U2^T = U1 X2 U2^T
+// (each product undoes the transpose of the one before).  "S" is V1, V2, U1^T, U2^T for H and
+// U1, U2, V1^T, V2^T for H^T: the host keeps both orientations of the four factors resident (2 MB).
+//
+// Block tile T x T (T = 128: 4 waves as 2x2, each 2x2 MFMA tiles of 32x32; 64: 4 waves, 1 tile each; 32: one
+// wave), K step 32, synchronous global->LDS staging (latency covered by the other resident blocks).  Epilogues fuse the spectral multiplier, the residual + per-tile loss partial, and the
+// -2 * clip-mask scaling; PRECLIP clamps IN on the fly (the data term's final clip).
 #include "nhmc_common.h"
 
 namespace {
@@ -26,21 +29,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3 };
 constexpr int BK = 32;
 
-template <int T, int NW, bool LEFT, int EPI, bool PRECLIP>
-__global__ __launch_bounds__(64 * NW * NW) void k_sgemm(
-    const float* __restrict__ X, const float* __restrict__ S, float* __restrict__ Cout,
+template <int T, int NW, int EPI, bool PRECLIP>
+__global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
+    const float* __restrict__ IN, const float* __restrict__ S, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int d, int channels) {
   constexpr int NT = 64 * NW * NW;
   constexpr int FR = T / (32 * NW);
-  constexpr int ALD = LEFT ? T : BK + 1;
-  __shared__ float As[LEFT ? BK * T : T * (BK + 1)];
+  constexpr int NV = (BK * T / 4) / NT;          // float4 per thread per operand tile
+  __shared__ float As[BK * T];
   __shared__ float Bs[BK * T];
 
-  const int img = blockIdx.z, ti = blockIdx.y * T, tj = blockIdx.x * T;
+  const int img = blockIdx.z, tr = blockIdx.y * T, tc = blockIdx.x * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / NW, wj = wave % NW;
   const int lr = lane & 31, lh = lane >> 5;
-  const float* __restrict__ Ximg = X + (int64_t)img * d * d;
+  const float* __restrict__ Ximg = IN + (int64_t)img * d * d;
 
   f32x16 acc[FR][FR];
 #pragma unroll
@@ -50,36 +53,20 @@ __global__ __launch_bounds__(64 * NW * NW) void k_sgemm(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
+  // Synchronous staging: with 3-4 blocks resident per CU the other blocks' MFMAs cover the global-load
+  // latency; register prefetch and LDS double buffering measured 5-10 % SLOWER here (scratch/gemm_bench.hip:
+  // 57 us vs 61-69 us per 192-image product), because they cost registers and a second barrier.
   for (int k0 = 0; k0 < d; k0 += BK) {
-    // ---- stage A ----
-    if (LEFT) {
 #pragma unroll
-      for (int v = 0; v < (BK * T / 4) / NT; ++v) {
-        const int idx = tid + v * NT, kk = idx / (T / 4), c4 = idx % (T / 4);
-        *reinterpret_cast<float4*>(&As[kk * T + c4 * 4]) =
-            *reinterpret_cast<const float4*>(&S[(int64_t)(k0 + kk) * d + ti + c4 * 4]);
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + v * NT, kk = idx / (T / 4), c4 = idx % (T / 4);
+      nhmc_v4f pa = *reinterpret_cast<const nhmc_v4f*>(&Ximg[(int64_t)(k0 + kk) * d + tr + c4 * 4]);
+      const nhmc_v4f pb = *reinterpret_cast<const nhmc_v4f*>(&S[(int64_t)(k0 + kk) * d + tc + c4 * 4]);
+      if (PRECLIP) {
+        pa.x = nhmc_clip1(pa.x); pa.y = nhmc_clip1(pa.y); pa.z = nhmc_clip1(pa.z); pa.w = nhmc_clip1(pa.w);
       }
-    } else {
-#pragma unroll
-      for (int v = 0; v < (BK * T / 4) / NT; ++v) {
-        const int idx = tid + v * NT, r = idx / (BK / 4), c4 = idx % (BK / 4);
-        const float4 val = *reinterpret_cast<const float4*>(&Ximg[(int64_t)(ti + r) * d + k0 + c4 * 4]);
-        float* dst = &As[r * (BK + 1) + c4 * 4];
-        dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
-      }
-    }
-    // ---- stage B ----
-    {
-      const float* __restrict__ src = LEFT ? Ximg : S;
-#pragma unroll
-      for (int v = 0; v < (BK * T / 4) / NT; ++v) {
-        const int idx = tid + v * NT, kk = idx / (T / 4), c4 = idx % (T / 4);
-        float4 val = *reinterpret_cast<const float4*>(&src[(int64_t)(k0 + kk) * d + tj + c4 * 4]);
-        if (LEFT && PRECLIP) {
-          val.x = nhmc_clip1(val.x); val.y = nhmc_clip1(val.y); val.z = nhmc_clip1(val.z); val.w = nhmc_clip1(val.w);
-        }
-        *reinterpret_cast<float4*>(&Bs[kk * T + c4 * 4]) = val;
-      }
+      *reinterpret_cast<nhmc_v4f*>(&As[kk * T + c4 * 4]) = pa;
+      *reinterpret_cast<nhmc_v4f*>(&Bs[kk * T + c4 * 4]) = pb;
     }
     __syncthreads();
 #pragma unroll 4
@@ -87,8 +74,7 @@ __global__ __launch_bounds__(64 * NW * NW) void k_sgemm(
       float a[FR], b[FR];
 #pragma unroll
       for (int f = 0; f < FR; ++f) {
-        const int row = (wi * FR + f) * 32 + lr;
-        a[f] = LEFT ? As[(kk + lh) * ALD + row] : As[row * ALD + kk + lh];
+        a[f] = As[(kk + lh) * T + (wi * FR + f) * 32 + lr];
         b[f] = Bs[(kk + lh) * T + (wj * FR + f) * 32 + lr];
       }
 #pragma unroll
@@ -101,29 +87,34 @@ __global__ __launch_bounds__(64 * NW * NW) void k_sgemm(
   }
 
   // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  // Wave-uniform image bases + one 32-bit per-lane offset: 64-bit per-element addresses for three arrays cost
+  // ~90 VGPRs and halved the occupancy of the MULD / RESID / GRAD variants.
   const int c = img % channels;
+  float* __restrict__ out_img = OUT + (int64_t)img * d * d;
+  const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * d * d : nullptr;
+  const float* __restrict__ aux_img = aux ? aux + (int64_t)img * d * d : nullptr;
   float lsum = 0.0f;
 #pragma unroll
   for (int fa = 0; fa < FR; ++fa)
 #pragma unroll
-    for (int fb = 0; fb < FR; ++fb)
+    for (int fb = 0; fb < FR; ++fb) {
+      const int base = (tr + (wi * FR + fa) * 32 + 4 * lh) * d + tc + (wj * FR + fb) * 32 + lr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = ti + (wi * FR + fa) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int col = tj + (wj * FR + fb) * 32 + lr;
-        const int64_t off = (int64_t)row * d + col;
+        const int off = base + ((r & 3) + 8 * (r >> 2)) * d;
         float v = acc[fa][fb][r];
-        if (EPI == EPI_MULD) v = v * Dmap[(int64_t)c * d * d + off];
+        if (EPI == EPI_MULD) v = v * dm_img[off];
         if (EPI == EPI_RESID) {
-          v = aux[(int64_t)img * d * d + off] - v;        // r = y - H x
+          v = aux_img[off] - v;                           // r = y - H x
           lsum += v * v;
         }
         if (EPI == EPI_GRAD) {
           v = -(2.0f * v);
-          if (aux) v = v * nhmc_in1(aux[(int64_t)img * d * d + off]);
+          if (aux_img) v = v * nhmc_in1(aux_img[off]);
         }
-        Cout[(int64_t)img * d * d + off] = v;
+        out_img[off] = v;
       }
+    }
   if (EPI == EPI_RESID) {
     __shared__ double red[NW * NW];
     double s = nhmc_wave_sum((double)lsum);
@@ -139,18 +130,18 @@ __global__ __launch_bounds__(64 * NW * NW) void k_sgemm(
   }
 }
 
-template <bool LEFT, int EPI, bool PRECLIP>
-int gemm(const float* X, const float* S, float* Cout, const float* Dmap, const float* aux, double* ws, int n_img,
+template <int EPI, bool PRECLIP>
+int gemm(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
          int channels, int d, hipStream_t st) {
   if (d % 128 == 0) {
     dim3 grid(d / 128, d / 128, n_img);
-    NHMC_LAUNCH((k_sgemm<128, 2, LEFT, EPI, PRECLIP>), grid, dim3(256), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
+    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, d, channels);
   } else if (d % 64 == 0) {
     dim3 grid(d / 64, d / 64, n_img);
-    NHMC_LAUNCH((k_sgemm<64, 2, LEFT, EPI, PRECLIP>), grid, dim3(256), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
+    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, d, channels);
   } else {
     dim3 grid(d / 32, d / 32, n_img);
-    NHMC_LAUNCH((k_sgemm<32, 1, LEFT, EPI, PRECLIP>), grid, dim3(64), 0, st, X, S, Cout, Dmap, aux, ws, d, channels);
+    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, d, channels);
   }
   return nhmc_launch_status();
 }
@@ -169,7 +160,7 @@ extern "C" int nhmc_spectral_tiles(int channels, int dim) {
 }
 
 // out_c = Lo (D_c o (L^T X_c R)) Ro^T.  Arguments: L and R as stored ([d][d] row-major), LoT = Lo^T and
-// RoT = Ro^T as stored (see the layout note at the top).
+// RoT = Ro^T as stored.
 extern "C" int nhmc_spectral_apply(const float* x, const float* L, const float* R, const float* Dmap,
                                    const float* LoT, const float* RoT, float* out, float* tmp, int n_chains,
                                    int channels, int dim, nhmc_stream_t stream) {
@@ -181,10 +172,10 @@ extern "C" int nhmc_spectral_apply(const float* x, const float* L, const float* 
   hipStream_t st = nhmc_s(stream);
   const int n = n_chains * channels;
   int rc;
-  if ((rc = gemm<true, EPI_NONE, false>(x, L, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<false, EPI_MULD, false>(tmp, R, out, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<true, EPI_NONE, false>(out, LoT, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  return gemm<false, EPI_NONE, false>(tmp, RoT, out, nullptr, nullptr, nullptr, n, channels, dim, st);
+  if ((rc = gemm<EPI_NONE, false>(x, L, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;     // X^T L
+  if ((rc = gemm<EPI_MULD, false>(tmp, R, out, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;       // (L^T X R) o D
+  if ((rc = gemm<EPI_NONE, false>(out, LoT, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;  // (Lo .)^T
+  return gemm<EPI_NONE, false>(tmp, RoT, out, nullptr, nullptr, nullptr, n, channels, dim, st);                 // Lo . Ro^T
 }
 
 // Data term for the spectral operator.  `factors` is the packed resident block [8][d][d] (row-major):
@@ -206,14 +197,14 @@ extern "C" int nhmc_data_spectral(const float* xt, const float* y, const float* 
   float* B = tmp + (int64_t)n * dd;
   int rc;
   // r = y - U1 (D o (V1^T clip(xt) V2)) U2^T
-  if (apply_clip) { if ((rc = gemm<true, EPI_NONE, true>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
-  else            { if ((rc = gemm<true, EPI_NONE, false>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
-  if ((rc = gemm<false, EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<true, EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<false, EPI_RESID, false>(A, U2T, B, nullptr, y, loss_ws, n, channels, dim, st))) return rc;
+  if (apply_clip) { if ((rc = gemm<EPI_NONE, true>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
+  else            { if ((rc = gemm<EPI_NONE, false>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
+  if ((rc = gemm<EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_RESID, false>(A, U2T, B, nullptr, y, loss_ws, n, channels, dim, st))) return rc;
   // g = -2 V1 (D o (U1^T r U2)) V2^T  (x) mask
-  if ((rc = gemm<true, EPI_NONE, false>(B, U1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<false, EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<true, EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  return gemm<false, EPI_GRAD, false>(A, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, dim, st);
+  if ((rc = gemm<EPI_NONE, false>(B, U1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  return gemm<EPI_GRAD, false>(A, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, dim, st);
 }

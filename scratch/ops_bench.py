@@ -1,0 +1,35 @@
+import sys, time, torch
+sys.path.insert(0, '.')
+import nhmc.kernels as K
+from nhmc import operators
+dev = torch.device('cuda')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+def timeit(f, n=20):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+x = K.randn_philox((B, 3, 256, 256), 1, 0, 0)
+T = B * 3 * 256 * 256 * 4
+op = operators.build_operator('deblur_aniso', 3, 256, dev)
+y = K.randn_philox((B, 3, 256, 256), 1, 0, 1).reshape(B, -1)
+ms = timeit(lambda: op.data_term(x, y, True), 10)
+fl = 8 * B * 3 * 2 * 256 ** 3
+print(f'aniso data term B={B}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)')
+ms = timeit(lambda: op.H(x), 10)
+print(f'aniso H B={B}: {ms:.3f} ms  {fl/2/ms/1e9:.1f} TFLOP/s')
+op4 = operators.build_operator('sr4', 3, 256, dev)
+y4 = torch.randn(B, op4.M, device=dev)
+ms = timeit(lambda: op4.data_term(x, y4, True))
+print(f'sr4 data term B={B}: {ms*1e3:.1f} us  {(2*T)/ms/1e6:.0f} GB/s (2T)')
+op16 = operators.build_operator('sr16', 3, 256, dev)
+y16 = torch.randn(B, op16.M, device=dev)
+ms = timeit(lambda: op16.data_term(x, y16, True))
+print(f'sr16 data term B={B}: {ms*1e3:.1f} us  {(2*T)/ms/1e6:.0f} GB/s (2T)')
+opi = operators.build_operator('inpaint_random', 3, 256, dev)
+yi = torch.randn(B, opi.M, device=dev)
+ms = timeit(lambda: opi.data_term(x, yi, True))
+print(f'inpaint data term B={B}: {ms*1e3:.1f} us  {(2*T)/ms/1e6:.0f} GB/s (2T dense)')
