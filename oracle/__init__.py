@@ -18,4 +18,4 @@ reference itself, produced in the build container by `oracle/gen_golden.py`
 `tests/test_oracle_golden.py` replays every fixture through this package.
 """
 
-from . import schedule, operators, ddim, hmc_ref, philox_ref, tiny_score  # noqa: F401
+from . import schedule, operators, ddim, hmc_ref, latent_ref, philox_ref, tiny_score  # noqa: F401
