@@ -27,6 +27,7 @@ def test_g7_first_trajectory_per_chain_form(golden):
     model = latent_ref.TinyLatentModel()
     op = oops.InpaintRef(3, 64, T(g['missing']))
     out = latent_ref.trajectory_latent(T(g['x']), T(g['p0']), SEQ, SEQ_NEXT, model, op, T(g['y_0']),
-                                       sigma_y=float(g['sigma_y']), eps=float(g['epsilon']), m=1.0, L=3)
+                                       sigma_y=float(g['sigma_y']), eps=float(g['epsilon']), m=1.0,
+                                       L=int(float(g['tau']) / float(g['epsilon'])))   # floor(0.3/0.1) == 2 in fp64
     # per-chain loss is a row-wise sum (the reference sums the whole batch): same value to fp32 rounding of H
     assert abs(float((out['H1'] - out['H0'])[0]) + float(g['neg_dH'][0])) < 0.01
