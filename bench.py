@@ -46,11 +46,13 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--chunk', type=int, default=16, help='chains per score-network call (activation memory)')
+    ap.add_argument('--chunk', type=int, default=32, help='chains per score-network call (activation memory)')
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='chains per GPU (BASELINE: 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-only', action='store_true', help='skip the end-to-end steps (profiling the HIP kernels)')
     ap.add_argument('--roofline-launches', type=int, default=200)
+    ap.add_argument('--rehearse-shared-gpu', action='store_true',
+                    help='rehearsal only: all ranks use cuda:0 over gloo (checks the N>1 control flow on a 1-GPU box)')
     return ap.parse_args()
 
 
@@ -180,7 +182,11 @@ def main():
     import nhmc.kernels as K
     from nhmc import sampler, sharding
     assert torch.cuda.is_available(), 'bench.py needs a GPU; the HIP path has no CPU fallback'
-    rank, local_rank, world = sharding.init_process_group()
+    if args.rehearse_shared_gpu:
+        rank, local_rank, world = sharding.init_process_group('gloo')
+        local_rank = 0
+    else:
+        rank, local_rank, world = sharding.init_process_group()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local_rank)

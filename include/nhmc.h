@@ -137,6 +137,17 @@ int nhmc_sr_H(const float* x, float* y, int ratio, int n_chains, int channels, i
 int nhmc_sr_Ht(const float* y, float* x, int ratio, float scale, int n_chains, int channels,
                int dim, nhmc_stream_t stream);
 
+/* Colorization (Hfuncs.py:655-695): y = sum_c w_c x_c per pixel.  w: HOST array of `channels` (<= 4) weights
+ * (passed by value to the kernel); for nhmc_color_Ht pass w_c for H^T and w_c / |w|^2 for H^+.
+ * loss partials: nhmc_color_tiles(hw) per chain. */
+int nhmc_color_tiles(int64_t hw);
+int nhmc_data_color(const float* xt, const float* y, const float* w, int apply_clip, float* g_xt,
+                    double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
+int nhmc_color_H(const float* x, const float* w, float* y, int n_chains, int channels, int64_t hw,
+                 nhmc_stream_t stream);
+int nhmc_color_Ht(const float* y, const float* w, float* x, int n_chains, int channels, int64_t hw,
+                  nhmc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a15  Spectral (anisotropic-blur) operator   Hfuncs.py:448-523
  *   out_c = Lo (D_c o (L^T X_c R)) Ro^T      (H: L,R = V1,V2, Lo,Ro = U1,U2; H^T swaps them)
@@ -194,6 +205,27 @@ int nhmc_accept_commit(const int32_t* accept, const int32_t* epoch, float* x, co
 int nhmc_schedule_end(const int32_t* accept, const int32_t* active, int32_t* epoch,
                       int32_t* rejected, double* tau, double* eps, int32_t* n_accept,
                       int32_t* n_reject, int n_chains, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Latent variant (hmc_latent)                   main_sampling_latent.py:691-733
+ * The epoch index is the shared loop counter there (a reject consumes its epoch), so the host passes
+ * what depends on it: final_phase = (epoch >= epochs) and sigma_y_on_accept =
+ * sigma_y0*(sigma_0/sigma_y0)**(epoch/epochs) (annealing) or sigma_0 (final phase).
+ * nhmc_latent_commit: accepted chains push their PREVIOUS accepted decode xt_last into a ring of the last
+ *   `keep` samples when final_phase && has_prev (samples: [n_chains][keep][n_elem], slot count % keep;
+ *   :709 runs before :713), then xt_last <- xt_prop, x <- x_prop.  Call before nhmc_schedule_end_latent.
+ * nhmc_schedule_end_latent: accept -> rejected = 0, sigma_y = sigma_y_on_accept, final phase also tau = 0.1,
+ *   eps = 0.01 and count += has_prev; has_prev = 1.  reject -> rejected += 1; at 2: tau *= 0.9, eps *= 0.9,
+ *   rejected = 0.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_latent_commit(const int32_t* accept, const int32_t* has_prev, const int32_t* count,
+                       int final_phase, int keep, float* x, const float* x_prop, float* xt_last,
+                       const float* xt_prop, float* samples, int n_chains, int64_t n_elem,
+                       nhmc_stream_t stream);
+int nhmc_schedule_end_latent(const int32_t* accept, int32_t* rejected, double* tau, double* eps,
+                             double* sigma_y, int32_t* count, int32_t* has_prev, int32_t* n_accept,
+                             double sigma_y_on_accept, int final_phase, int n_chains,
+                             nhmc_stream_t stream);
 
 /* PSNR of clamp((xt+1)/2,0,1) against clamp((x_orig+1)/2,0,1)   main_sampling.py:738-739
  * ws: double[n_chains][nhmc_data_tiles(n_elem)]. */

@@ -32,6 +32,10 @@ SIGNATURES = {
     'nhmc_inpaint_Ht': (I, [P, P, P, I, I64, I64, P]),
     'nhmc_sr_H': (I, [P, P, I, I, I, I, P]),
     'nhmc_sr_Ht': (I, [P, P, I, F, I, I, I, P]),
+    'nhmc_color_tiles': (I, [I64]),
+    'nhmc_data_color': (I, [P, P, P, I, P, P, I, I, I64, P]),
+    'nhmc_color_H': (I, [P, P, P, I, I, I64, P]),
+    'nhmc_color_Ht': (I, [P, P, P, I, I, I64, P]),
     'nhmc_spectral_apply': (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     'nhmc_spectral_tiles': (I, [I, I]),
     'nhmc_data_spectral': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
@@ -40,6 +44,8 @@ SIGNATURES = {
     'nhmc_schedule_begin': (I, [P, P, P, P, P, P, D, I, I, I, P]),
     'nhmc_accept_commit': (I, [P, P, P, P, P, P, I, I, I, I64, P]),
     'nhmc_schedule_end': (I, [P, P, P, P, P, P, P, P, I, P]),
+    'nhmc_latent_commit': (I, [P, P, P, I, I, P, P, P, P, P, I, I64, P]),
+    'nhmc_schedule_end_latent': (I, [P, P, P, P, P, P, P, P, D, I, I, P]),
     'nhmc_psnr': (I, [P, P, P, P, I, I64, P]),
     'nhmc_randn_philox': (I, [P, U64, U32, U32, F, I, I64, P]),
     'nhmc_uniform_philox': (I, [P, U64, U32, U32, I, P]),

@@ -1,0 +1,119 @@
+// Colorization operator (row f.3 of SURVEY.md section 8: remaining linear operators on the data-term interface).
+// Replaces obs_functions/Hfuncs.py:655-695: per pixel y = sum_c w_c x_c (w = U s V^T of the 1x3 matrix
+// [0.3333 0.3334 0.3333]), H^T y = w_c y, H^+ y = w_c y / |w|^2.  One thread owns a float4 of pixels and reads the
+// C channel planes at the same offset: coalesced 16-byte accesses, nothing to stage or shuffle.
+// HBM-bound: data term R xt (T) + R y (T/C) + W g (T).
+#include "nhmc_common.h"
+
+namespace {
+
+constexpr int MAXC = 4;
+struct W { float w[MAXC]; };
+
+// MODE 0: data term, 1: H, 2: H^T / H^+ (weights already scaled by the host)
+template <int MODE>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__ xin, const float4* __restrict__ yin,
+                                                      float4* __restrict__ out, W wt, int channels, int apply_clip,
+                                                      double* __restrict__ loss_ws, int64_t hw4) {
+  const int chain = blockIdx.y;
+  const int64_t q = (int64_t)blockIdx.x * NHMC_BLOCK + threadIdx.x;
+  const bool live = q < hw4;
+  float acc = 0.0f;
+  if (live) {
+    const int64_t xbase = (int64_t)chain * channels * hw4, ybase = (int64_t)chain * hw4;
+    if (MODE == 2) {
+      const float4 y = nhmc_ldnt(&yin[ybase + q]);
+      for (int c = 0; c < channels; ++c) {
+        float4 o;
+        o.x = wt.w[c] * y.x; o.y = wt.w[c] * y.y; o.z = wt.w[c] * y.z; o.w = wt.w[c] * y.w;
+        nhmc_stnt(&out[xbase + (int64_t)c * hw4 + q], o);
+      }
+    } else {
+      float4 xv[MAXC];
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        if (c < channels) {
+          xv[c] = nhmc_ldnt(&xin[xbase + (int64_t)c * hw4 + q]);
+          const float* e = reinterpret_cast<const float*>(&xv[c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s[k] += wt.w[c] * ((MODE == 0 && apply_clip) ? nhmc_clip1(e[k]) : e[k]);
+        }
+      }
+      if (MODE == 1) {
+        nhmc_stnt(&out[ybase + q], make_float4(s[0], s[1], s[2], s[3]));
+      } else {
+        const float4 y = nhmc_ldnt(&yin[ybase + q]);
+        const float r[4] = {y.x - s[0], y.y - s[1], y.z - s[2], y.w - s[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += r[k] * r[k];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          if (c < channels) {
+            const float* e = reinterpret_cast<const float*>(&xv[c]);
+            float4 o;
+            float* oe = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float gr = -(2.0f * r[k]) * wt.w[c];
+              if (apply_clip) gr = gr * nhmc_in1(e[k]);
+              oe[k] = gr;
+            }
+            nhmc_stnt(&out[xbase + (int64_t)c * hw4 + q], o);
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 0) {
+    __shared__ double red[4];
+    double v[1] = {(double)acc};
+    nhmc_block_sum<1>(v, red);
+    if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
+  }
+}
+
+bool bad(int n_chains, int channels, int64_t hw) {
+  return n_chains <= 0 || n_chains > 65535 || channels <= 0 || channels > MAXC || hw <= 0 || (hw & 3);
+}
+
+template <int MODE>
+int launch(const float* xin, const float* yin, float* out, const float* w_host, int channels, int apply_clip,
+           double* ws, int n_chains, int64_t hw, hipStream_t st) {
+  W wt;
+  for (int c = 0; c < MAXC; ++c) wt.w[c] = c < channels ? w_host[c] : 0.0f;
+  const int64_t hw4 = hw / 4;
+  dim3 grid((unsigned)((hw4 + NHMC_BLOCK - 1) / NHMC_BLOCK), (unsigned)n_chains);
+  NHMC_LAUNCH((k_color<MODE>), grid, dim3(NHMC_BLOCK), 0, st, (const float4*)xin, (const float4*)yin, (float4*)out, wt,
+              channels, apply_clip, ws, hw4);
+  return nhmc_launch_status();
+}
+
+}  // namespace
+
+extern "C" int nhmc_color_tiles(int64_t hw) { return (int)((hw / 4 + NHMC_BLOCK - 1) / NHMC_BLOCK); }
+
+// w: HOST array of `channels` weights (they travel as a kernel argument).
+extern "C" int nhmc_data_color(const float* xt, const float* y, const float* w, int apply_clip, float* g_xt,
+                               double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream) {
+  if (!xt || !y || !w || !g_xt || !loss_ws) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, hw)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y) || !nhmc_aligned16(g_xt)) return NHMC_ERR_ALIGN;
+  return launch<0>(xt, y, g_xt, w, channels, apply_clip, loss_ws, n_chains, hw, nhmc_s(stream));
+}
+
+extern "C" int nhmc_color_H(const float* x, const float* w, float* y, int n_chains, int channels, int64_t hw,
+                            nhmc_stream_t stream) {
+  if (!x || !w || !y) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, hw)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(x) || !nhmc_aligned16(y)) return NHMC_ERR_ALIGN;
+  return launch<1>(x, nullptr, y, w, channels, 0, nullptr, n_chains, hw, nhmc_s(stream));
+}
+
+extern "C" int nhmc_color_Ht(const float* y, const float* w, float* x, int n_chains, int channels, int64_t hw,
+                             nhmc_stream_t stream) {
+  if (!x || !w || !y) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, hw)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(x) || !nhmc_aligned16(y)) return NHMC_ERR_ALIGN;
+  return launch<2>(nullptr, y, x, w, channels, 0, nullptr, n_chains, hw, nhmc_s(stream));
+}

@@ -109,6 +109,51 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_accept_commit(
   }
 }
 
+// ---- latent variant (main_sampling_latent.py:691-733) ------------------------------------------
+// Accepted chains: in the final phase the PREVIOUS accepted decode is appended to a ring of the last `keep`
+// samples (:709 appends x_accept before :713 reassigns it), then xt_last <- xt_prop and x <- x_prop.
+__global__ __launch_bounds__(NHMC_BLOCK) void k_latent_commit(
+    const int32_t* __restrict__ accept, const int32_t* __restrict__ has_prev, const int32_t* __restrict__ count,
+    int final_phase, int keep, float4* __restrict__ x, const float4* __restrict__ x_prop, float4* __restrict__ xt_last,
+    const float4* __restrict__ xt_prop, float4* __restrict__ samples, int64_t n4) {
+  const int chain = blockIdx.y;
+  if (!accept[chain]) return;
+  const bool push = final_phase && has_prev[chain] && samples;
+  const int64_t base = (int64_t)chain * n4;
+  const int64_t sbase = ((int64_t)chain * keep + (push ? count[chain] % keep : 0)) * n4;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    if (push) nhmc_stnt(&samples[sbase + q], nhmc_ldnt(&xt_last[base + q]));
+    nhmc_stnt(&xt_last[base + q], nhmc_ldnt(&xt_prop[base + q]));
+    nhmc_stnt(&x[base + q], nhmc_ldnt(&x_prop[base + q]));
+  }
+}
+
+__global__ void k_schedule_end_latent(const int32_t* __restrict__ accept, int32_t* __restrict__ rejected,
+                                      double* __restrict__ tau, double* __restrict__ eps, double* __restrict__ sigma_y,
+                                      int32_t* __restrict__ count, int32_t* __restrict__ has_prev,
+                                      int32_t* __restrict__ n_accept, double sigma_y_on_accept, int final_phase,
+                                      int n_chains) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chains) return;
+  if (accept[c]) {
+    rejected[c] = 0;
+    sigma_y[c] = sigma_y_on_accept;                       // :693-695 (annealing) or :705-706 (sigma_0)
+    if (final_phase) {
+      tau[c] = 0.1; eps[c] = 0.01;                        // :707-708
+      if (has_prev[c]) count[c] += 1;                     // :709
+    }
+    has_prev[c] = 1;
+    if (n_accept) n_accept[c] += 1;
+  } else {
+    rejected[c] += 1;
+    if (rejected[c] >= 2) { tau[c] = tau[c] * 0.9; eps[c] = eps[c] * 0.9; rejected[c] = 0; }   // :728-732
+  }
+}
+
 // ---- PSNR -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(NHMC_BLOCK) void k_psnr_partial(const float4* __restrict__ xt,
                                                              const float4* __restrict__ xo, double* __restrict__ ws,
@@ -268,6 +313,33 @@ extern "C" int nhmc_accept_commit(const int32_t* accept, const int32_t* epoch, f
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
   NHMC_LAUNCH(k_accept_commit, grid, block, 0, nhmc_s(stream), accept, epoch, (float4*)x,
                      (const float4*)x_prop, (const float4*)xt_prop, (float4*)samples, epochs, sampling, n_elem / 4);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_latent_commit(const int32_t* accept, const int32_t* has_prev, const int32_t* count,
+                                  int final_phase, int keep, float* x, const float* x_prop, float* xt_last,
+                                  const float* xt_prop, float* samples, int n_chains, int64_t n_elem,
+                                  nhmc_stream_t stream) {
+  if (!accept || !has_prev || !count || !x || !x_prop || !xt_last || !xt_prop || keep <= 0 || n_chains <= 0 ||
+      n_elem <= 0)
+    return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || !nhmc_aligned16(x) || !nhmc_aligned16(x_prop) || !nhmc_aligned16(xt_last) ||
+      !nhmc_aligned16(xt_prop) || !nhmc_aligned16(samples))
+    return NHMC_ERR_ALIGN;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  NHMC_LAUNCH(k_latent_commit, grid, block, 0, nhmc_s(stream), accept, has_prev, count, final_phase, keep, (float4*)x,
+              (const float4*)x_prop, (float4*)xt_last, (const float4*)xt_prop, (float4*)samples, n_elem / 4);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_schedule_end_latent(const int32_t* accept, int32_t* rejected, double* tau, double* eps,
+                                        double* sigma_y, int32_t* count, int32_t* has_prev, int32_t* n_accept,
+                                        double sigma_y_on_accept, int final_phase, int n_chains,
+                                        nhmc_stream_t stream) {
+  if (!accept || !rejected || !tau || !eps || !sigma_y || !count || !has_prev || n_chains <= 0) return NHMC_ERR_ARG;
+  NHMC_LAUNCH(k_schedule_end_latent, small_grid(n_chains), dim3(256), 0, nhmc_s(stream), accept, rejected, tau, eps,
+              sigma_y, count, has_prev, n_accept, sigma_y_on_accept, final_phase, n_chains);
   return nhmc_launch_status();
 }
 

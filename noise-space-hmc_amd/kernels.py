@@ -200,6 +200,43 @@ def sr_Ht(y, ratio, channels, dim, scale):
     return x
 
 
+def _host_w(w):
+    arr = (C.c_float * len(w))(*[float(v) for v in w])
+    return C.cast(arr, C.c_void_p), arr
+
+
+def data_color(xt, y, w, apply_clip=True):
+    """w: sequence of per-channel weights (host) -> (loss [B] float64, g_xt)"""
+    lib = _lib.load()
+    B, Cc, hw = xt.shape[0], xt.shape[1], xt[0, 0].numel()
+    tiles = lib.nhmc_color_tiles(hw)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    g = torch.empty_like(xt)
+    wp, keep = _host_w(w)
+    rc = lib.nhmc_data_color(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), wp, int(apply_clip), _p(g), _p(ws),
+                             B, Cc, hw, _stream())
+    _lib.check(rc, 'nhmc_data_color')
+    return sum_partials(ws, tiles, B), g
+
+
+def color_H(x, w):
+    lib = _lib.load()
+    B, Cc, hw = x.shape[0], x.shape[1], x[0, 0].numel()
+    y = torch.empty(B, hw, dtype=torch.float32, device=x.device)
+    wp, keep = _host_w(w)
+    _lib.check(lib.nhmc_color_H(_p(x, torch.float32, 'x'), wp, _p(y), B, Cc, hw, _stream()), 'nhmc_color_H')
+    return y
+
+
+def color_Ht(y, w, channels):
+    lib = _lib.load()
+    B, hw = y.shape
+    x = torch.empty(B, channels * hw, dtype=torch.float32, device=y.device)
+    wp, keep = _host_w(w)
+    _lib.check(lib.nhmc_color_Ht(_p(y, torch.float32, 'y'), wp, _p(x), B, channels, hw, _stream()), 'nhmc_color_Ht')
+    return x
+
+
 def spectral_apply(x, L, R, Dmap, LoT, RoT):
     """out_c = Lo (D_c o (L^T X_c R)) Ro^T ; x: [B,C,d,d]"""
     lib = _lib.load()
@@ -278,6 +315,26 @@ def schedule_end(accept, state):
                                _p(state.get('n_accept'), torch.int32), _p(state.get('n_reject'), torch.int32),
                                B, _stream())
     _lib.check(rc, 'nhmc_schedule_end')
+
+
+def latent_commit(accept, st, final_phase, keep, x, x_prop, xt_last, xt_prop, samples):
+    lib = _lib.load()
+    B, N = _chains_elems(x)
+    rc = lib.nhmc_latent_commit(_p(accept, torch.int32), _p(st['has_prev'], torch.int32), _p(st['count'], torch.int32),
+                                int(final_phase), int(keep), _p(x, torch.float32, 'x'), _p(x_prop, torch.float32, 'x_prop'),
+                                _p(xt_last, torch.float32, 'xt_last'), _p(xt_prop, torch.float32, 'xt_prop'),
+                                _p(samples, torch.float32, 'samples'), B, N, _stream())
+    _lib.check(rc, 'nhmc_latent_commit')
+
+
+def schedule_end_latent(accept, st, sigma_y_on_accept, final_phase):
+    lib = _lib.load()
+    rc = lib.nhmc_schedule_end_latent(_p(accept, torch.int32), _p(st['rejected'], torch.int32), _p(st['tau'], torch.float64),
+                                      _p(st['eps'], torch.float64), _p(st['sigma_y'], torch.float64),
+                                      _p(st['count'], torch.int32), _p(st['has_prev'], torch.int32),
+                                      _p(st.get('n_accept'), torch.int32), float(sigma_y_on_accept), int(final_phase),
+                                      accept.numel(), _stream())
+    _lib.check(rc, 'nhmc_schedule_end_latent')
 
 
 def psnr(xt, x_orig):

@@ -180,6 +180,41 @@ class Deblurring2D(H_functions):
         return K.data_spectral(xt, y.reshape(xt.shape).contiguous(), self.factors, self.Dmap, apply_clip)
 
 
+class Deblurring(Deblurring2D):
+    """obs_functions/Hfuncs.py:236-316 (`deblur_gauss`): the same spectral form with one 1-D kernel on both
+    axes -- and the same tiled-singulars / interleaved-Vt multiplier layout (:308-309 vs :265-271)."""
+
+    def __init__(self, kernel, channels, img_dim, device, ZERO=3e-2):
+        super().__init__(kernel, kernel, channels, img_dim, device, zero=ZERO)
+
+
+class Colorization(H_functions):
+    """obs_functions/Hfuncs.py:655-695: y = 0.3333 r + 0.3334 g + 0.3333 b per pixel (via the SVD of that row)."""
+
+    def __init__(self, img_dim, device):
+        self.channels, self.img_dim, self.device = 3, img_dim, device
+        U, s, Vh = torch.linalg.svd(torch.tensor([[0.3333, 0.3334, 0.3333]]))
+        self._s = float(s[0])
+        self.w = [float(U[0, 0] * s[0] * Vh[0, c]) for c in range(3)]           # H = U s V^T
+        self.w_pinv = [wc / self._s ** 2 for wc in self.w]
+        self.M = img_dim * img_dim
+
+    def singulars(self):
+        return torch.full((self.M,), self._s, device=self.device)
+
+    def H(self, vec):
+        return K.color_H(_img(vec, self.channels, self.img_dim), self.w)
+
+    def Ht(self, vec):
+        return K.color_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.w, self.channels)
+
+    def H_pinv(self, vec):
+        return K.color_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.w_pinv, self.channels)
+
+    def data_term(self, xt, y, apply_clip=True):
+        return K.data_color(xt, y, self.w, apply_clip)
+
+
 def gaussian_taps(sigma, half=4):
     """main_sampling.py:327-335."""
     k = torch.tensor([math.exp(-0.5 * (x / sigma) ** 2) for x in range(-half, half + 1)], dtype=torch.float32)
@@ -202,4 +237,8 @@ def build_operator(deg, channels, img_dim, device, generator=None):
         return Inpainting(channels, img_dim, torch.nonzero(missing.view(-1)).squeeze(1), device)
     if deg == 'deblur_aniso':
         return Deblurring2D(gaussian_taps(1.0), gaussian_taps(20.0), channels, img_dim, device)
+    if deg == 'deblur_gauss':
+        return Deblurring(gaussian_taps(10.0, half=2), channels, img_dim, device)           # main_sampling.py:308-314
+    if deg == 'color':
+        return Colorization(img_dim, device)
     raise NotImplementedError(f'degradation {deg!r} is outside the HMC hot path of this build')

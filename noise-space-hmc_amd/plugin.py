@@ -100,3 +100,11 @@ class HMC(Base_Algo):
     @staticmethod
     def fused_step_vjp(gout, xt, e, at, at_next, final_clip=False, gout2=None):
         return K.ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=final_clip, gout2=gout2)
+
+
+class HMCLatent(HMC):
+    """Drop-in for `Unconditional_Latent` (algos/unconditional_latent.py) under `--algo hmc_latent`: the score is
+    the latent-diffusion model's `apply_model(xt, t, None)` (:12); the DDIM arithmetic is the same kernels."""
+
+    def score(self, xt, t):
+        return self.model.apply_model(xt, t, None)

@@ -94,12 +94,16 @@ class LeapfrogEngine:
     chunk      chains per score-network call (activation memory of 3 graphs scales with it)
     """
 
-    def __init__(self, score, operator, b, seq, seq_next, device, chunk=None):
+    def __init__(self, score, operator, b, seq, seq_next, device, chunk=None, alpha_table=None, image_map=None):
+        """alpha_table (optional, instead of betas `b`): entry k = alpha-bar at t = k-1, as the latent driver builds
+        it from the model's buffers (main_sampling_latent.py:771-773).  image_map (optional): differentiable torch
+        map applied to the clipped decode before the operator (the latent variant's first-stage decoder, :651)."""
         self.score, self.operator, self.device, self.chunk = score, operator, device, chunk
+        self.image_map = image_map
         steps = list(zip(reversed(seq), reversed(seq_next)))
-        idx = torch.tensor([[i + 1, j + 1] for i, j in steps], device=b.device)
         from .schedule import alpha_bar_table
-        table = alpha_bar_table(b)
+        table = alpha_table.to(device).float() if alpha_table is not None else alpha_bar_table(b)
+        idx = torch.tensor([[i + 1, j + 1] for i, j in steps], device=table.device)
         self.t_values = [float(i) for i, _ in steps]
         self.at = [table[idx[s, 0]].reshape(1).to(device) for s in range(len(steps))]
         self.at_next = [table[idx[s, 1]].reshape(1).to(device) for s in range(len(steps))]
@@ -137,7 +141,15 @@ class LeapfrogEngine:
             outs.append(e)
         xt_out.copy_(cur)
         # the final clip is applied by the last mix; its mask is re-derived inside the last mix backward
-        l, g = self.operator.data_term(cur, y, apply_clip=False)
+        if self.image_map is None:
+            l, g = self.operator.data_term(cur, y, apply_clip=False)
+        else:
+            zleaf = cur.detach().requires_grad_(True)
+            with torch.enable_grad():
+                img = self.image_map(zleaf)
+            l, g_img = self.operator.data_term(img.detach().contiguous(), y, apply_clip=False)
+            (g,) = torch.autograd.grad(img, zleaf, g_img)
+            g = g.contiguous()
         loss_out.copy_(l)
         g2 = None
         for s in reversed(range(S)):
@@ -281,6 +293,69 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
 
     res = hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
                      chunk=getattr(opt, 'score_chunk', None), log=None if quiet else log)
+    return res.samples[0] if n == 1 else res.samples
+
+
+# --------------------------------------------------------------------------------------------- #
+# latent variant
+# --------------------------------------------------------------------------------------------- #
+def hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, epochs=50, sampling=10,
+                      chunk=None, collect_trace=False):
+    """Per-chain form of `hmc_latent` (main_sampling_latent.py:623-762).  The epoch index is the shared loop
+    counter (a reject consumes its epoch, :646,733); sigma_y / tau / eps / reject counter / sample ring are per
+    chain.  Returns SimpleNamespace(samples [B, <=sampling latents...] as a list per chain, x, n_accept, trace)."""
+    device = x.device
+    B, N = x.shape[0], x[0].numel()
+    model = algo.model
+    tau, epsilon, m = float(opt.tau), float(opt.epsilon), float(getattr(opt, 'm', 1.0))
+    sigma_0, sigma_y0 = float(opt.sigma_0), float(opt.sigma_y)
+    L = max(1, math.floor(tau / epsilon))
+    noise = noise or TorchNoise()
+    if not hasattr(H_funcs, 'data_term'):
+        raise TypeError('H_funcs must be an nhmc.operators operator (needs the fused data_term)')
+    table = torch.cat([model.alphas_cumprod_prev[0:1], model.alphas_cumprod], dim=0)          # :771-773
+    engine = LeapfrogEngine(algo.score, H_funcs, None, seq, seq_next, device, chunk=chunk, alpha_table=table,
+                            image_map=model.differentiable_decode_first_stage)
+    x = x.detach().clone().contiguous()
+    y_0 = y_0.contiguous()
+    st = ChainState(B, tau, epsilon, device)
+    st.t['sigma_y'].fill_(sigma_y0)
+    st.t['count'] = torch.zeros(B, dtype=torch.int32, device=device)
+    st.t['has_prev'] = torch.zeros(B, dtype=torch.int32, device=device)
+    ring = torch.zeros((B, sampling) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
+    xt_last = torch.zeros_like(x)
+    ws = K.leapfrog_ws(B, N, device)
+    trace = [] if collect_trace else None
+    for epoch in range(epochs + 2 * sampling):
+        st['eps_eff'].copy_(st['eps'])
+        p = noise.momentum(epoch, x, math.sqrt(m))
+        out = run_trajectory(engine, x, p, y_0, st, m, L, ws)
+        u = noise.uniform(epoch, B, device)
+        accept, dH = K.metropolis(out['H0'], out['H1'], u, None)
+        final = epoch >= epochs
+        sig_next = sigma_0 if final else sigma_y0 * (sigma_0 / sigma_y0) ** (epoch / epochs)   # :693-695,705-706
+        if collect_trace:
+            trace.append(dict(dH=dH.cpu(), accept=accept.cpu(), sigma_y=st['sigma_y'].cpu().clone(), eps=st['eps'].cpu().clone()))
+        K.latent_commit(accept, st, final, sampling, x, out['x_prop'], xt_last, out['xt'], ring)
+        K.schedule_end_latent(accept, st, sig_next, final)
+    count = st['count'].cpu().tolist()
+    samples = []
+    for c in range(B):                                                       # last `sampling` pushes, oldest first
+        k = min(count[c], sampling)
+        order = [(count[c] - k + j) % sampling for j in range(k)]
+        samples.append(ring[c, order])
+    return SimpleNamespace(samples=samples, x=x, n_accept=st['n_accept'], count=count, trace=trace, xt=xt_last, L=L)
+
+
+def hmc_latent(x, n, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
+    """Reference entry point (main_sampling_latent.py:623, called at :466): returns the stack of the last 10
+    collected latents at n = 1; a list of such stacks for n > 1 (the reference raises there)."""
+    noise = getattr(opt, 'noise_source', None)
+    if noise is None:
+        seed = getattr(opt, 'philox_seed', None)
+        noise = PhiloxNoise(seed, getattr(opt, 'chain_id0', 0)) if seed is not None else TorchNoise()
+    res = hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
+                            chunk=getattr(opt, 'score_chunk', None))
     return res.samples[0] if n == 1 else res.samples
 
 

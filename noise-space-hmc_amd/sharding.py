@@ -71,6 +71,8 @@ def gather_chains(local, n_chains, rank=None, world=None):
 
 def max_over_ranks(value, device):
     """Scalar max over ranks (bench timing contract)."""
+    if dist.is_initialized() and dist.get_backend() == 'gloo':
+        device = torch.device('cpu')
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

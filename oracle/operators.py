@@ -163,6 +163,29 @@ class SpectralBlurRef:
         return self._sandwich(self.U1, Y, self.U2, Dp, self.V1, self.V2).reshape(Y.shape[0], -1)
 
 
+class ColorRef:
+    """Hfuncs.py:655-695 (Colorization): y = U00 * s * sum_c V[c,0] x_c per pixel with the SVD of
+    [[0.3333, 0.3334, 0.3333]]; H^T spreads w_c y, H^+ spreads w_c y / s^2."""
+
+    def __init__(self, img_dim):
+        self.channels, self.img_dim, self.M = 3, img_dim, img_dim * img_dim
+        U, s, V = torch.svd(torch.Tensor([[0.3333, 0.3334, 0.3333]]), some=False)
+        self.s = s[0]
+        self.w = (U[0, 0] * s[0]) * V[:, 0]
+
+    def H(self, x):
+        B = x.shape[0]
+        return (x.reshape(B, 3, -1) * self.w.view(1, 3, 1)).sum(1)
+
+    def Ht(self, y):
+        B = y.shape[0]
+        return (y.reshape(B, 1, -1) * self.w.view(1, 3, 1)).reshape(B, -1)
+
+    def H_pinv(self, y):
+        B = y.shape[0]
+        return (y.reshape(B, 1, -1) * (self.w / self.s ** 2).view(1, 3, 1)).reshape(B, -1)
+
+
 def random_inpaint_missing(img_dim, frac=0.92, generator=None):
     """main_sampling.py:302-305: whole RGB triples at randperm(H*W)[:0.92 H*W]."""
     hw = img_dim * img_dim
