@@ -148,6 +148,19 @@ int nhmc_color_H(const float* x, const float* w, float* y, int n_chains, int cha
 int nhmc_color_Ht(const float* y, const float* w, float* x, int n_chains, int channels, int64_t hw,
                   nhmc_stream_t stream);
 
+/* Walsh-Hadamard compressive sensing (Hfuncs.py:611-651): y[k*C + c] = (FWHT(x_c) / d)[perm[k]], k < d*d/ratio;
+ * H^T = H^+.  kslot: int32[d*d], position -> k or -1 (inverse of perm restricted to the kept rows).  m = row length
+ * of y (= C*d*d/ratio).  dim: power of two, 16..256.  tmp: float[n_chains*C*d*d] (x2 for the data term).
+ * loss partials: nhmc_cs_tiles(channels, dim) per chain. */
+int nhmc_cs_tiles(int channels, int dim);
+int nhmc_cs_H(const float* x, const int32_t* kslot, float* y, float* tmp, int n_chains, int channels, int dim,
+              int64_t m, nhmc_stream_t stream);
+int nhmc_cs_Ht(const float* y, const int32_t* kslot, float* x, float* tmp, int n_chains, int channels, int dim,
+               int64_t m, nhmc_stream_t stream);
+int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslot, int apply_clip, float* g_xt,
+                 double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
+                 nhmc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a15  Spectral (anisotropic-blur) operator   Hfuncs.py:448-523
  *   out_c = Lo (D_c o (L^T X_c R)) Ro^T      (H: L,R = V1,V2, Lo,Ro = U1,U2; H^T swaps them)
@@ -167,6 +180,19 @@ int nhmc_spectral_tiles(int channels, int dim);
 int nhmc_data_spectral(const float* xt, const float* y, const float* factors, const float* Dmap,
                        int apply_clip, float* g_xt, double* loss_ws, float* tmp,
                        int n_chains, int channels, int dim, nhmc_stream_t stream);
+
+/* Separable strided convolution (SRConv / sr_bicubic, Hfuncs.py:527-607): H(X) = A X A^T, A [sd][d] the
+ * (singular-value-truncated) 1-D kernel matrix; H^T(Y) = A^T Y A; H^+(Y) = A+ Y A+^T.  Same MFMA kernel, rectangular.
+ * nhmc_sandwich_rect: t = in^T S1, out = t^T S2 with in [K1][R1], S1 [K1][C1], S2 [R1][C2] -> out [C1][C2] per image
+ *   (all dims % 32 == 0); tmp: float[n_img*R1*C1].   H: in = X, S1 = S2 = A^T;  H^T: in = Y, S1 = S2 = A.
+ * nhmc_data_srconv: r = y - A clip(xt) A^T, loss partials (nhmc_srconv_tiles per chain), g = -2 A^T r A (masked).
+ *   At = A^T as stored [d][sd], A [sd][d];  tmp: float[n_chains*C*(2*d*sd + sd*sd)]. */
+int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, float* out, float* tmp, int n_img,
+                       int K1, int R1, int C1, int C2, nhmc_stream_t stream);
+int nhmc_srconv_tiles(int channels, int small_dim);
+int nhmc_data_srconv(const float* xt, const float* y, const float* At, const float* A, int apply_clip,
+                     float* g_xt, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
+                     int small_dim, nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a5  Hamiltonian                          main_sampling.py:697,717-718

@@ -36,9 +36,16 @@ SIGNATURES = {
     'nhmc_data_color': (I, [P, P, P, I, P, P, I, I, I64, P]),
     'nhmc_color_H': (I, [P, P, P, I, I, I64, P]),
     'nhmc_color_Ht': (I, [P, P, P, I, I, I64, P]),
+    'nhmc_cs_tiles': (I, [I, I]),
+    'nhmc_cs_H': (I, [P, P, P, P, I, I, I, I64, P]),
+    'nhmc_cs_Ht': (I, [P, P, P, P, I, I, I, I64, P]),
+    'nhmc_data_cs': (I, [P, P, P, I, P, P, P, I, I, I, I64, P]),
     'nhmc_spectral_apply': (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     'nhmc_spectral_tiles': (I, [I, I]),
     'nhmc_data_spectral': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
+    'nhmc_sandwich_rect': (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    'nhmc_srconv_tiles': (I, [I, I]),
+    'nhmc_data_srconv': (I, [P, P, P, P, I, P, P, P, I, I, I, I, P]),
     'nhmc_hamiltonian': (I, [P, I, P, P, D, P, P, I, P]),
     'nhmc_metropolis': (I, [P, P, P, P, P, P, I, P]),
     'nhmc_schedule_begin': (I, [P, P, P, P, P, P, D, I, I, I, P]),

@@ -1,0 +1,226 @@
+// Walsh-Hadamard compressive-sensing operator (row f.3 of SURVEY.md section 8).
+// Replaces obs_functions/Hfuncs.py:611-651 (WalshHadamardCS): with F = FWHT / d (orthonormal, self-inverse) on each
+// d x d channel image flattened row-major,   y[k*C + c] = F(x_c)[perm[k]]  for k < d^2/ratio,   H^T = H^+ = F(scatter).
+//
+// F over d^2 = 2^(2 log2 d) points factors as F_d (x) F_d: the first log2 d butterfly stages act inside rows
+// (contiguous), the last log2 d across rows -- the same stage order and pairing as the reference's loop (:613-621),
+// so the transform is bit-exact against it.
+//   pass A (k_fwht_rows):  a lane owns V = max(1, d/64) consecutive elements of a row; stages h < V in registers,
+//                          stages h >= V with __shfl_xor inside the row's lane group.  No LDS.  Optional prologue:
+//                          clip (data term) or gather from y through the slot map (H^T).
+//   pass B (k_fwht_cols):  a block stages a d x PC column panel in LDS (PC*4 = 128-byte row segments), runs the
+//                          log2 d row-index stages there (consecutive threads -> consecutive columns: conflict-free),
+//                          scales by 1/d and applies the epilogue: plain store, scatter to y (H), residual against
+//                          y + loss partial (data term, writes the zero-filled spectrum for the adjoint), or
+//                          -2 * clip-mask (data-term gradient).
+// HBM-bound: each pass reads and writes the image once (2T); a data term is 4 passes.
+#include "nhmc_common.h"
+
+namespace {
+
+enum { PRO_NONE = 0, PRO_CLIP = 1, PRO_GATHER = 2 };
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_RESID = 2, EPI_GRAD = 3 };
+
+template <int V> struct Vec;
+template <> struct Vec<1> { typedef float type; };
+template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// ---- pass A: rows -------------------------------------------------------------------------------------
+template <int V, int PRO>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_rows(const float* __restrict__ in, const float* __restrict__ y,
+                                                          const int32_t* __restrict__ kslot, float* __restrict__ out,
+                                                          int d, int channels, int64_t m, int64_t total_rows) {
+  const int lpr = d / V;                               // lanes per row (<= 64)
+  const int rows_per_wave = NHMC_WAVE / lpr;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (NHMC_BLOCK / NHMC_WAVE) + (threadIdx.x >> 6);
+  const int64_t row = wave * rows_per_wave + lane / lpr;            // global row over [chain][channel][i]
+  const int j0 = (lane % lpr) * V;
+  const bool live = row < total_rows;
+  float v[V];
+  if (live) {
+    const int64_t base = row * d + j0;
+    if (PRO == PRO_GATHER) {
+      const int64_t plane = row / d;                                // chain*channels + c
+      const int c = (int)(plane % channels);
+      const int64_t chain = plane / channels;
+      const int64_t q = (row % d) * d + j0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const int k = kslot[q + e];
+        v[e] = k >= 0 ? y[chain * m + (int64_t)k * channels + c] : 0.0f;
+      }
+    } else {
+      typename Vec<V>::type w = *reinterpret_cast<const typename Vec<V>::type*>(&in[base]);   // V*4-byte aligned: d % V == 0
+      const float* we = reinterpret_cast<const float*>(&w);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = PRO == PRO_CLIP ? nhmc_clip1(we[e]) : we[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.0f;
+  }
+  // in-register stages h = 1 .. V/2
+#pragma unroll
+  for (int h = 1; h < V; h <<= 1) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if ((e & h) == 0) {
+        const float a = v[e], b = v[e + h];
+        v[e] = a + b;
+        v[e + h] = a - b;
+      }
+    }
+  }
+  // cross-lane stages h = V .. d/2  <->  lane xor (h / V)
+  for (int s = 1; s < lpr; s <<= 1) {
+    const bool upper = (lane & s) != 0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float other = __shfl_xor(v[e], s, NHMC_WAVE);
+      v[e] = upper ? other - v[e] : v[e] + other;
+    }
+  }
+  if (live) {
+    const int64_t base = row * d + j0;
+    typename Vec<V>::type w;
+    float* we = reinterpret_cast<float*>(&w);
+#pragma unroll
+    for (int e = 0; e < V; ++e) we[e] = v[e];
+    *reinterpret_cast<typename Vec<V>::type*>(&out[base]) = w;
+  }
+}
+
+// ---- pass B: columns ----------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restrict__ in, float* __restrict__ out,
+                                                          const float* __restrict__ y, float* __restrict__ y_out,
+                                                          const int32_t* __restrict__ kslot, const float* __restrict__ xt,
+                                                          double* __restrict__ loss_ws, int d, int pc, int channels,
+                                                          int64_t m, int apply_clip) {
+  extern __shared__ float tile[];                                   // [d][pc]
+  const int64_t plane = blockIdx.y;                                 // chain*channels + c
+  const int c0 = blockIdx.x * pc;
+  const int c = (int)(plane % channels);
+  const int64_t chain = plane / channels;
+  const float* __restrict__ src = in + plane * (int64_t)d * d;
+  const int n = d * pc;
+  for (int idx = threadIdx.x; idx < n; idx += NHMC_BLOCK) {
+    const int i = idx / pc, cc = idx % pc;
+    tile[idx] = src[(int64_t)i * d + c0 + cc];
+  }
+  __syncthreads();
+  for (int h = 1; h < d; h <<= 1) {
+    for (int idx = threadIdx.x; idx < n / 2; idx += NHMC_BLOCK) {
+      const int cc = idx % pc, pr = idx / pc;                       // pair number -> lower row index
+      const int i = (pr / h) * 2 * h + (pr % h);
+      const float a = tile[i * pc + cc], b = tile[(i + h) * pc + cc];
+      tile[i * pc + cc] = a + b;
+      tile[(i + h) * pc + cc] = a - b;
+    }
+    __syncthreads();
+  }
+  const float scale = 1.0f / (float)d;                              // fwht(...) / img_dim  (:622)
+  float acc = 0.0f;
+  for (int idx = threadIdx.x; idx < n; idx += NHMC_BLOCK) {
+    const int i = idx / pc, cc = idx % pc;
+    const int64_t q = (int64_t)i * d + c0 + cc;                     // position inside the plane
+    const int64_t off = plane * (int64_t)d * d + q;
+    float v = tile[idx] * scale;
+    if (EPI == EPI_STORE) {
+      out[off] = v;
+    } else if (EPI == EPI_SCATTER) {
+      const int k = kslot[q];
+      if (k >= 0) y_out[chain * m + (int64_t)k * channels + c] = v;
+    } else if (EPI == EPI_RESID) {
+      const int k = kslot[q];
+      float r = 0.0f;
+      if (k >= 0) { r = y[chain * m + (int64_t)k * channels + c] - v; acc += r * r; }
+      out[off] = r;                                                 // zero-filled spectrum of the residual
+    } else {
+      v = -(2.0f * v);
+      if (apply_clip) v = v * nhmc_in1(xt[off]);
+      out[off] = v;
+    }
+  }
+  if (EPI == EPI_RESID) {
+    __shared__ double red[4];
+    double s[1] = {(double)acc};
+    nhmc_block_sum<1>(s, red);
+    if (threadIdx.x == 0) loss_ws[plane * gridDim.x + blockIdx.x] = s[0];
+  }
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+bool bad(int n_chains, int channels, int dim) {
+  return n_chains <= 0 || channels <= 0 || !pow2(dim) || dim < 16 || dim > 1024 || (int64_t)n_chains * channels > 65535;
+}
+int panel_cols(int dim) { int pc = 8192 / dim; return pc > dim ? dim : (pc < 8 ? 8 : pc); }   // d*pc*4 B <= 32 KiB (d <= 1024)
+
+template <int PRO>
+int rows(const float* in, const float* y, const int32_t* kslot, float* out, int n_chains, int channels, int dim,
+         int64_t m, hipStream_t st) {
+  const int64_t total_rows = (int64_t)n_chains * channels * dim;
+  const int V = dim >= 256 ? 4 : (dim >= 128 ? 2 : 1);
+  const int rows_per_wave = NHMC_WAVE / (dim / V);
+  const int64_t waves = (total_rows + rows_per_wave - 1) / rows_per_wave;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(NHMC_BLOCK);
+  if (dim / V > 64) return NHMC_ERR_SHAPE;
+  if (V == 4) NHMC_LAUNCH((k_fwht_rows<4, PRO>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows);
+  else if (V == 2) NHMC_LAUNCH((k_fwht_rows<2, PRO>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows);
+  else NHMC_LAUNCH((k_fwht_rows<1, PRO>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows);
+  return nhmc_launch_status();
+}
+
+template <int EPI>
+int cols(const float* in, float* out, const float* y, float* y_out, const int32_t* kslot, const float* xt, double* ws,
+         int n_chains, int channels, int dim, int64_t m, int apply_clip, hipStream_t st) {
+  const int pc = panel_cols(dim);
+  dim3 grid((unsigned)(dim / pc), (unsigned)(n_chains * channels)), block(NHMC_BLOCK);
+  NHMC_LAUNCH((k_fwht_cols<EPI>), grid, block, (size_t)dim * pc * sizeof(float), st, in, out, y, y_out, kslot, xt, ws,
+              dim, pc, channels, m, apply_clip);
+  return nhmc_launch_status();
+}
+
+}  // namespace
+
+extern "C" int nhmc_cs_tiles(int channels, int dim) { return channels * (dim / panel_cols(dim)); }
+
+// y = H x.  kslot: int32[dim*dim], position -> k (row of y) or -1 when perm^-1(position) >= dim^2/ratio.
+// tmp: float[n_chains*channels*dim*dim].
+extern "C" int nhmc_cs_H(const float* x, const int32_t* kslot, float* y, float* tmp, int n_chains, int channels,
+                         int dim, int64_t m, nhmc_stream_t stream) {
+  if (!x || !kslot || !y || !tmp || m <= 0) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim) || dim > 256) return NHMC_ERR_SHAPE;
+  int rc = rows<PRO_NONE>(x, nullptr, nullptr, tmp, n_chains, channels, dim, m, nhmc_s(stream));
+  if (rc) return rc;
+  return cols<EPI_SCATTER>(tmp, nullptr, nullptr, y, kslot, nullptr, nullptr, n_chains, channels, dim, m, 0, nhmc_s(stream));
+}
+
+// x = H^T y = H^+ y.
+extern "C" int nhmc_cs_Ht(const float* y, const int32_t* kslot, float* x, float* tmp, int n_chains, int channels,
+                          int dim, int64_t m, nhmc_stream_t stream) {
+  if (!x || !kslot || !y || !tmp || m <= 0) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim) || dim > 256) return NHMC_ERR_SHAPE;
+  int rc = rows<PRO_GATHER>(nullptr, y, kslot, tmp, n_chains, channels, dim, m, nhmc_s(stream));
+  if (rc) return rc;
+  return cols<EPI_STORE>(tmp, x, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, m, 0, nhmc_s(stream));
+}
+
+// loss partials (nhmc_cs_tiles per chain) and g_xt = -2 H^T (y - H clip(xt)) (x) mask.  tmp: 2 images worth.
+extern "C" int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslot, int apply_clip, float* g_xt,
+                            double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
+                            nhmc_stream_t stream) {
+  if (!xt || !y || !kslot || !g_xt || !loss_ws || !tmp || m <= 0) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim) || dim > 256) return NHMC_ERR_SHAPE;
+  hipStream_t st = nhmc_s(stream);
+  float* A = tmp;
+  float* B = tmp + (int64_t)n_chains * channels * dim * dim;
+  int rc;
+  if (apply_clip) { if ((rc = rows<PRO_CLIP>(xt, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc; }
+  else            { if ((rc = rows<PRO_NONE>(xt, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc; }
+  if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
+  if ((rc = rows<PRO_NONE>(B, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
+  return cols<EPI_GRAD>(A, g_xt, nullptr, nullptr, nullptr, xt, nullptr, n_chains, channels, dim, m, apply_clip, st);
+}

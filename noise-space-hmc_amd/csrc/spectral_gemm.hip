@@ -32,7 +32,8 @@ constexpr int BK = 32;
 template <int T, int NW, int EPI, bool PRECLIP>
 __global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
     const float* __restrict__ IN, const float* __restrict__ S, float* __restrict__ OUT,
-    const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int d, int channels) {
+    const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int K, int R, int C,
+    int channels) {
   constexpr int NT = 64 * NW * NW;
   constexpr int FR = T / (32 * NW);
   constexpr int NV = (BK * T / 4) / NT;          // float4 per thread per operand tile
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / NW, wj = wave % NW;
   const int lr = lane & 31, lh = lane >> 5;
-  const float* __restrict__ Ximg = IN + (int64_t)img * d * d;
+  const float* __restrict__ Ximg = IN + (int64_t)img * K * R;       // IN: [K][R], S: [K][C], OUT: [R][C]
 
   f32x16 acc[FR][FR];
 #pragma unroll
@@ -56,12 +57,12 @@ __global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
   // Synchronous staging: with 3-4 blocks resident per CU the other blocks' MFMAs cover the global-load
   // latency; register prefetch and LDS double buffering measured 5-10 % SLOWER here (scratch/gemm_bench.hip:
   // 57 us vs 61-69 us per 192-image product), because they cost registers and a second barrier.
-  for (int k0 = 0; k0 < d; k0 += BK) {
+  for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int idx = tid + v * NT, kk = idx / (T / 4), c4 = idx % (T / 4);
-      nhmc_v4f pa = *reinterpret_cast<const nhmc_v4f*>(&Ximg[(int64_t)(k0 + kk) * d + tr + c4 * 4]);
-      const nhmc_v4f pb = *reinterpret_cast<const nhmc_v4f*>(&S[(int64_t)(k0 + kk) * d + tc + c4 * 4]);
+      nhmc_v4f pa = *reinterpret_cast<const nhmc_v4f*>(&Ximg[(int64_t)(k0 + kk) * R + tr + c4 * 4]);
+      const nhmc_v4f pb = *reinterpret_cast<const nhmc_v4f*>(&S[(int64_t)(k0 + kk) * C + tc + c4 * 4]);
       if (PRECLIP) {
         pa.x = nhmc_clip1(pa.x); pa.y = nhmc_clip1(pa.y); pa.z = nhmc_clip1(pa.z); pa.w = nhmc_clip1(pa.w);
       }
@@ -90,18 +91,18 @@ __global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
   // Wave-uniform image bases + one 32-bit per-lane offset: 64-bit per-element addresses for three arrays cost
   // ~90 VGPRs and halved the occupancy of the MULD / RESID / GRAD variants.
   const int c = img % channels;
-  float* __restrict__ out_img = OUT + (int64_t)img * d * d;
-  const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * d * d : nullptr;
-  const float* __restrict__ aux_img = aux ? aux + (int64_t)img * d * d : nullptr;
+  float* __restrict__ out_img = OUT + (int64_t)img * R * C;
+  const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * R * C : nullptr;
+  const float* __restrict__ aux_img = aux ? aux + (int64_t)img * R * C : nullptr;
   float lsum = 0.0f;
 #pragma unroll
   for (int fa = 0; fa < FR; ++fa)
 #pragma unroll
     for (int fb = 0; fb < FR; ++fb) {
-      const int base = (tr + (wi * FR + fa) * 32 + 4 * lh) * d + tc + (wj * FR + fb) * 32 + lr;
+      const int base = (tr + (wi * FR + fa) * 32 + 4 * lh) * C + tc + (wj * FR + fb) * 32 + lr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int off = base + ((r & 3) + 8 * (r >> 2)) * d;
+        const int off = base + ((r & 3) + 8 * (r >> 2)) * C;
         float v = acc[fa][fb][r];
         if (EPI == EPI_MULD) v = v * dm_img[off];
         if (EPI == EPI_RESID) {
@@ -124,26 +125,32 @@ __global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
       double tot = 0.0;
       for (int w = 0; w < NW * NW; ++w) tot += red[w];
       // tiles of one chain are contiguous: [chain][channel][tile_row][tile_col]
-      const int tiles_side = d / T;
-      ws[((int64_t)img * tiles_side + blockIdx.y) * tiles_side + blockIdx.x] = tot;
+      ws[((int64_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
     }
   }
+}
+
+int tile_of2(int R, int C) { return (R % 128 == 0 && C % 128 == 0) ? 128 : ((R % 64 == 0 && C % 64 == 0) ? 64 : 32); }
+
+// OUT[R][C] = IN[K][R]^T * S[K][C] per image; K % 32 == 0, R % 32 == 0, C % 32 == 0.
+template <int EPI, bool PRECLIP>
+int gemm_krc(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
+             int channels, int K, int R, int C, hipStream_t st) {
+  const int T = tile_of2(R, C);
+  dim3 grid(C / T, R / T, n_img);
+  if (T == 128)
+    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels);
+  else if (T == 64)
+    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels);
+  else
+    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels);
+  return nhmc_launch_status();
 }
 
 template <int EPI, bool PRECLIP>
 int gemm(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
          int channels, int d, hipStream_t st) {
-  if (d % 128 == 0) {
-    dim3 grid(d / 128, d / 128, n_img);
-    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, d, channels);
-  } else if (d % 64 == 0) {
-    dim3 grid(d / 64, d / 64, n_img);
-    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, d, channels);
-  } else {
-    dim3 grid(d / 32, d / 32, n_img);
-    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, d, channels);
-  }
-  return nhmc_launch_status();
+  return gemm_krc<EPI, PRECLIP>(IN, S, OUT, Dmap, aux, ws, n_img, channels, d, d, d, st);
 }
 
 int tile_of(int d) { return d % 128 == 0 ? 128 : (d % 64 == 0 ? 64 : 32); }
@@ -207,4 +214,52 @@ extern "C" int nhmc_data_spectral(const float* xt, const float* y, const float* 
   if ((rc = gemm<EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
   if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
   return gemm<EPI_GRAD, false>(A, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, dim, st);
+}
+
+// ---- separable strided convolution (SRConv, obs_functions/Hfuncs.py:527-607) ----------------------------------
+// H(X) = A X A^T with A [sd][d] (the truncated-SVD form of the 1-D strided kernel matrix); H^T(Y) = A^T Y A;
+// H^+(Y) = A+ Y A+^T.  All three are two products of the same kernel:  OUT = IN^T S.
+//   nhmc_sandwich_rect: out = M1^T-chain generic:  t = in^T S1 ([R1][C1]),  out = t^T S2 ([C1][C2]).
+extern "C" int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, float* out, float* tmp, int n_img,
+                                  int K1, int R1, int C1, int C2, nhmc_stream_t stream) {
+  if (!in || !S1 || !S2 || !out || !tmp) return NHMC_ERR_ARG;
+  if (n_img <= 0 || n_img > 65535 || (K1 % 32) || (R1 % 32) || (C1 % 32) || (C2 % 32) || K1 <= 0 || R1 <= 0 || C1 <= 0 || C2 <= 0)
+    return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(in) || !nhmc_aligned16(S1) || !nhmc_aligned16(S2) || !nhmc_aligned16(out) || !nhmc_aligned16(tmp))
+    return NHMC_ERR_ALIGN;
+  hipStream_t st = nhmc_s(stream);
+  int rc;
+  // t[R1][C1] = in[K1][R1]^T S1[K1][C1];   out[C1][C2] = t[R1][C1]^T S2[R1][C2]
+  if ((rc = gemm_krc<EPI_NONE, false>(in, S1, tmp, nullptr, nullptr, nullptr, n_img, 1, K1, R1, C1, st))) return rc;
+  return gemm_krc<EPI_NONE, false>(tmp, S2, out, nullptr, nullptr, nullptr, n_img, 1, R1, C1, C2, st);
+}
+
+extern "C" int nhmc_srconv_tiles(int channels, int small_dim) {
+  const int t = small_dim / tile_of2(small_dim, small_dim);
+  return channels * t * t;
+}
+
+// Data term: r = y - A clip(xt) A^T, loss partials (nhmc_srconv_tiles per chain), g = -2 A^T r A (x) mask.
+// At: A^T as stored ([d][sd] row-major), A: [sd][d].  tmp: float[n_img*(d*sd + sd*sd + sd*d)].
+extern "C" int nhmc_data_srconv(const float* xt, const float* y, const float* At, const float* A, int apply_clip,
+                                float* g_xt, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
+                                int small_dim, nhmc_stream_t stream) {
+  if (!xt || !y || !At || !A || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
+  if (n_chains <= 0 || channels <= 0 || (int64_t)n_chains * channels > 65535 || (dim % 32) || (small_dim % 32) ||
+      dim <= 0 || small_dim <= 0)
+    return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y) || !nhmc_aligned16(At) || !nhmc_aligned16(A) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(tmp))
+    return NHMC_ERR_ALIGN;
+  hipStream_t st = nhmc_s(stream);
+  const int n = n_chains * channels, d = dim, sd = small_dim;
+  float* T1 = tmp;                                    // [d][sd]
+  float* Rr = T1 + (int64_t)n * d * sd;               // [sd][sd]
+  float* T2 = Rr + (int64_t)n * sd * sd;              // [sd][d]
+  int rc;
+  if (apply_clip) { if ((rc = gemm_krc<EPI_NONE, true>(xt, At, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc; }
+  else            { if ((rc = gemm_krc<EPI_NONE, false>(xt, At, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc; }
+  if ((rc = gemm_krc<EPI_RESID, false>(T1, At, Rr, nullptr, y, loss_ws, n, channels, d, sd, sd, st))) return rc;   // r = y - A X A^T
+  if ((rc = gemm_krc<EPI_NONE, false>(Rr, A, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;  // r^T A
+  return gemm_krc<EPI_GRAD, false>(T2, A, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, sd, d, d, st);  // A^T r A
 }

@@ -237,6 +237,39 @@ def color_Ht(y, w, channels):
     return x
 
 
+def cs_H(x, kslot, m):
+    lib = _lib.load()
+    B, Cc, dim = x.shape[0], x.shape[1], x.shape[2]
+    y = torch.zeros(B, m, dtype=torch.float32, device=x.device)
+    tmp = torch.empty_like(x)
+    _lib.check(lib.nhmc_cs_H(_p(x, torch.float32, 'x'), _p(kslot, torch.int32), _p(y), _p(tmp), B, Cc, dim, m, _stream()),
+               'nhmc_cs_H')
+    return y
+
+
+def cs_Ht(y, kslot, channels, dim):
+    lib = _lib.load()
+    B, m = y.shape
+    x = torch.empty(B, channels, dim, dim, dtype=torch.float32, device=y.device)
+    tmp = torch.empty_like(x)
+    _lib.check(lib.nhmc_cs_Ht(_p(y, torch.float32, 'y'), _p(kslot, torch.int32), _p(x), _p(tmp), B, channels, dim, m,
+                              _stream()), 'nhmc_cs_Ht')
+    return x.reshape(B, -1)
+
+
+def data_cs(xt, y, kslot, apply_clip=True):
+    lib = _lib.load()
+    B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
+    tiles = lib.nhmc_cs_tiles(Cc, dim)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    g = torch.empty_like(xt)
+    rc = lib.nhmc_data_cs(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(kslot, torch.int32), int(apply_clip),
+                          _p(g), _p(ws), _p(tmp), B, Cc, dim, y.shape[1], _stream())
+    _lib.check(rc, 'nhmc_data_cs')
+    return sum_partials(ws, tiles, B), g
+
+
 def spectral_apply(x, L, R, Dmap, LoT, RoT):
     """out_c = Lo (D_c o (L^T X_c R)) Ro^T ; x: [B,C,d,d]"""
     lib = _lib.load()
@@ -247,6 +280,35 @@ def spectral_apply(x, L, R, Dmap, LoT, RoT):
                                  _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_spectral_apply')
     return out
+
+
+def sandwich_rect(x, S1, S2):
+    """x: [n_img, K1, R1]; t = x^T S1; out = t^T S2 -> [n_img, C1, C2]"""
+    lib = _lib.load()
+    n, K1, R1 = x.shape
+    C1, C2 = S1.shape[1], S2.shape[1]
+    if S1.shape[0] != K1 or S2.shape[0] != R1:
+        raise _lib.NhmcError('sandwich_rect: factor shapes do not chain')
+    out = torch.empty(n, C1, C2, dtype=torch.float32, device=x.device)
+    tmp = torch.empty(n, R1, C1, dtype=torch.float32, device=x.device)
+    rc = lib.nhmc_sandwich_rect(_p(x, torch.float32, 'x'), _p(S1, torch.float32), _p(S2, torch.float32), _p(out), _p(tmp),
+                                n, K1, R1, C1, C2, _stream())
+    _lib.check(rc, 'nhmc_sandwich_rect')
+    return out
+
+
+def data_srconv(xt, y, At, A, apply_clip=True):
+    lib = _lib.load()
+    B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
+    sd = A.shape[0]
+    tiles = lib.nhmc_srconv_tiles(Cc, sd)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    tmp = torch.empty(B * Cc * (2 * dim * sd + sd * sd), dtype=torch.float32, device=xt.device)
+    g = torch.empty_like(xt)
+    rc = lib.nhmc_data_srconv(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(At, torch.float32), _p(A, torch.float32),
+                              int(apply_clip), _p(g), _p(ws), _p(tmp), B, Cc, dim, sd, _stream())
+    _lib.check(rc, 'nhmc_data_srconv')
+    return sum_partials(ws, tiles, B), g
 
 
 def data_spectral(xt, y, factors, Dmap, apply_clip=True):

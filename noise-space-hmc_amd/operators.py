@@ -215,6 +215,100 @@ class Colorization(H_functions):
         return K.data_color(xt, y, self.w, apply_clip)
 
 
+class WalshHadamardCS(H_functions):
+    """obs_functions/Hfuncs.py:611-651: y[k*C + c] = (FWHT(x_c)/d)[perm[k]] for k < d^2/ratio; H^T = H^+."""
+
+    def __init__(self, channels, img_dim, ratio, perm, device):
+        self.channels, self.img_dim, self.ratio = channels, img_dim, ratio
+        hw = img_dim * img_dim
+        self.perm = perm
+        self.M = channels * hw // ratio
+        rows = self.M // channels
+        kslot = torch.full((hw,), -1, dtype=torch.int32)
+        kslot[perm.detach().cpu().long()[:rows]] = torch.arange(rows, dtype=torch.int32)
+        self.kslot = kslot.to(device)
+        self._singulars = torch.ones(self.M, device=device)
+
+    def singulars(self):
+        return self._singulars
+
+    def H(self, vec):
+        return K.cs_H(_img(vec, self.channels, self.img_dim), self.kslot, self.M)
+
+    def Ht(self, vec):
+        return K.cs_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.kslot, self.channels, self.img_dim)
+
+    H_pinv = Ht
+
+    def data_term(self, xt, y, apply_clip=True):
+        return K.data_cs(xt, y, self.kslot, apply_clip)
+
+
+def strided_conv_matrix(kernel, img_dim, stride):
+    """Hfuncs.py:543-553: [img_dim/stride, img_dim] strided 1-D convolution matrix with reflective padding."""
+    k = kernel.shape[0]
+    Hs = torch.zeros(img_dim // stride, img_dim)
+    for i in range(stride // 2, img_dim + stride // 2, stride):
+        for j in range(i - k // 2, i + k // 2):
+            je = -j - 1 if j < 0 else ((img_dim - 1) - (j - img_dim) if j >= img_dim else j)
+            Hs[i // stride, je] += kernel[j - i + k // 2]
+    return Hs
+
+
+class SRConv(H_functions):
+    """obs_functions/Hfuncs.py:527-607 (`sr_bicubicN`): H(X) = A X A^T per channel with A = U diag(s) V[:, :sd]^T the
+    SVD of the strided kernel matrix, singular values < 3e-2 zeroed (:557-558); here the channel interleave of the
+    singular values is consistent (`repeat_interleave`, :599), so the operator is the plain separable one."""
+
+    def __init__(self, kernel, channels, img_dim, device, stride=1):
+        self.channels, self.img_dim, self.ratio = channels, img_dim, stride
+        self.small_dim = sd = img_dim // stride
+        if img_dim % 32 or sd % 32:
+            raise NhmcError('SRConv needs img_dim and img_dim/stride to be multiples of 32')
+        Hs = strided_conv_matrix(kernel.detach().cpu().float(), img_dim, stride)
+        U, s, Vh = torch.linalg.svd(Hs, full_matrices=False)
+        s = torch.where(s < 3e-2, torch.zeros_like(s), s)
+        sinv = torch.where(s != 0, 1.0 / s, torch.zeros_like(s))
+        A = (U * s) @ Vh                                            # [sd, d]
+        Ap = (Vh.t() * sinv) @ U.t()                                # [d, sd]  pseudo-inverse
+        self.A, self.At = A.contiguous().to(device), A.t().contiguous().to(device)
+        self.ApT, self.Ap = Ap.t().contiguous().to(device), Ap.contiguous().to(device)
+        self.M = channels * sd * sd
+
+    def _planes(self, v, dim):
+        return v.reshape(-1, dim, dim).contiguous()
+
+    def H(self, vec):
+        B = vec.shape[0]
+        return K.sandwich_rect(self._planes(vec, self.img_dim), self.At, self.At).reshape(B, -1)       # A X A^T
+
+    def Ht(self, vec):
+        B = vec.shape[0]
+        return K.sandwich_rect(self._planes(vec, self.small_dim), self.A, self.A).reshape(B, -1)       # A^T Y A
+
+    def H_pinv(self, vec):
+        B = vec.shape[0]
+        return K.sandwich_rect(self._planes(vec, self.small_dim), self.ApT, self.ApT).reshape(B, -1)   # A+ Y A+^T
+
+    def data_term(self, xt, y, apply_clip=True):
+        return K.data_srconv(xt, y.contiguous(), self.At, self.A, apply_clip)
+
+
+def bicubic_taps(factor, a=-0.5):
+    """main_sampling.py:266-279."""
+    def w(x):
+        x = abs(x)
+        if x <= 1:
+            return (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1
+        if 1 < x < 2:
+            return a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a
+        return 0.0
+    import numpy as np
+    k = np.array([w((1 / factor) * (i - np.floor(factor * 4 / 2) + 0.5)) for i in range(factor * 4)])
+    k = torch.from_numpy(k / k.sum()).float()
+    return k / k.sum()
+
+
 def gaussian_taps(sigma, half=4):
     """main_sampling.py:327-335."""
     k = torch.tensor([math.exp(-0.5 * (x / sigma) ** 2) for x in range(-half, half + 1)], dtype=torch.float32)
@@ -223,6 +317,9 @@ def gaussian_taps(sigma, half=4):
 
 def build_operator(deg, channels, img_dim, device, generator=None):
     """`prepare_measurement` (main_sampling.py:261-351) for the degradations on the HMC hot path."""
+    if deg.startswith('sr_bicubic') and deg[10:].isdigit():
+        factor = int(deg[10:])
+        return SRConv(bicubic_taps(factor), channels, img_dim, device, stride=factor)
     if deg.startswith('sr') and deg[2:].isdigit():
         return SuperResolution(channels, img_dim, int(deg[2:]), device)
     if deg == 'inpaint_random':
@@ -241,4 +338,6 @@ def build_operator(deg, channels, img_dim, device, generator=None):
         return Deblurring(gaussian_taps(10.0, half=2), channels, img_dim, device)           # main_sampling.py:308-314
     if deg == 'color':
         return Colorization(img_dim, device)
+    if deg.startswith('cs') and deg[2:].isdigit():
+        return WalshHadamardCS(channels, img_dim, int(deg[2:]), torch.randperm(img_dim ** 2, generator=generator), device)
     raise NotImplementedError(f'degradation {deg!r} is outside the HMC hot path of this build')

@@ -186,6 +186,76 @@ class ColorRef:
         return (y.reshape(B, 1, -1) * (self.w / self.s ** 2).view(1, 3, 1)).reshape(B, -1)
 
 
+class WalshHadamardRef:
+    """Hfuncs.py:611-651 (WalshHadamardCS): orthonormal FWHT per channel image (butterflies h = 1, 2, 4, ... on the
+    row-major flattened image, then / img_dim, :613-623); rows perm[:d^2/ratio] are kept, interleaved (k, c)."""
+
+    def __init__(self, channels, img_dim, ratio, perm):
+        self.channels, self.img_dim, self.ratio, self.perm = channels, img_dim, ratio, perm.long()
+        self.M = channels * img_dim ** 2 // ratio
+
+    def fwht(self, vec):
+        B, n = vec.shape[0], self.img_dim ** 2
+        a = vec.reshape(B, self.channels, n)
+        h = 1
+        while h < n:
+            a = a.reshape(B, self.channels, -1, 2 * h)
+            lo, hi = a[..., :h], a[..., h:]
+            a = torch.cat([lo + hi, lo - hi], dim=-1)
+            h *= 2
+        return a.reshape(B, self.channels, n) / self.img_dim
+
+    def H(self, x):
+        B = x.shape[0]
+        return self.fwht(x)[:, :, self.perm].permute(0, 2, 1).reshape(B, -1)[:, :self.M]
+
+    def Ht(self, y):
+        B, n = y.shape[0], self.img_dim ** 2
+        full = torch.zeros(B, self.channels * n, dtype=y.dtype)
+        full[:, :self.M] = y.reshape(B, -1)
+        spec = torch.zeros(B, self.channels, n, dtype=y.dtype)
+        spec[:, :, self.perm] = full.reshape(B, n, self.channels).permute(0, 2, 1)
+        return self.fwht(spec).reshape(B, -1)
+
+    H_pinv = Ht
+
+
+class SeparableStridedRef:
+    """Hfuncs.py:527-607 (SRConv): H(X) = A X A^T with A = U diag(s) V[:, :sd]^T of the strided 1-D kernel matrix
+    (reflective padding :547-551; s < 3e-2 zeroed :557-558); H^T(Y) = A^T Y A; H^+(Y) = A+ Y A+^T."""
+
+    def __init__(self, kernel, channels, img_dim, stride):
+        self.channels, self.img_dim, self.small_dim = channels, img_dim, img_dim // stride
+        k, sd = kernel.shape[0], self.small_dim
+        Hs = torch.zeros(sd, img_dim)
+        for i in range(stride // 2, img_dim + stride // 2, stride):
+            for j in range(i - k // 2, i + k // 2):
+                je = j
+                if je < 0:
+                    je = -je - 1
+                if je >= img_dim:
+                    je = (img_dim - 1) - (je - img_dim)
+                Hs[i // stride, je] += kernel[j - i + k // 2]
+        U, s, V = torch.svd(Hs, some=False)
+        s = torch.where(s < 3e-2, torch.zeros_like(s), s)
+        sinv = torch.where(s != 0, 1 / s, torch.zeros_like(s))
+        self.A = (U * s) @ V[:, :sd].t()
+        self.Ap = (V[:, :sd] * sinv) @ U.t()
+        self.M = channels * sd * sd
+
+    def H(self, x):
+        X = x.reshape(x.shape[0], self.channels, self.img_dim, self.img_dim)
+        return (self.A @ X @ self.A.t()).reshape(x.shape[0], -1)
+
+    def Ht(self, y):
+        Y = y.reshape(y.shape[0], self.channels, self.small_dim, self.small_dim)
+        return (self.A.t() @ Y @ self.A).reshape(y.shape[0], -1)
+
+    def H_pinv(self, y):
+        Y = y.reshape(y.shape[0], self.channels, self.small_dim, self.small_dim)
+        return (self.Ap @ Y @ self.Ap.t()).reshape(y.shape[0], -1)
+
+
 def random_inpaint_missing(img_dim, frac=0.92, generator=None):
     """main_sampling.py:302-305: whole RGB triples at randperm(H*W)[:0.92 H*W]."""
     hw = img_dim * img_dim
