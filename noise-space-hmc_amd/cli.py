@@ -53,6 +53,8 @@ def get_parser():
     p.add_argument('--synthetic', type=int, default=0, help='use this many synthetic images')
     p.add_argument('--philox', action='store_true', help='counter-based, shard-invariant noise')
     p.add_argument('--save_images', action='store_true')
+    p.add_argument('--hmc_epochs', type=int, default=60, help='annealing epochs (reference: 60, main_sampling.py:665)')
+    p.add_argument('--hmc_sampling', type=int, default=20, help='collected samples (reference: 20, :666)')
     return p
 
 
@@ -119,6 +121,7 @@ def main(argv=None):
                          opt.synthetic, opt.seed)
     lo, hi = sharding.chain_range(images.shape[0], rank, world)
     opt.quiet = opt.chains > 1 or rank != 0
+    opt.progress_every = 10 if rank == 0 else 0                           # stderr heartbeat for long quiet runs
     if opt.philox:
         opt.philox_seed = opt.seed
     rows = []

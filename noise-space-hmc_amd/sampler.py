@@ -291,8 +291,17 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
         if getattr(opt, 'save_images', False):
             _save_png(out['xt'][0], os.path.join(opt.image_folder, f'hmc_{int(status[0][0])}.png'))
 
+    every = int(getattr(opt, 'progress_every', 0) or 0)
+
+    def progress(it, status, state, out, x_orig_):
+        if every and it % every == 0:
+            import sys
+            print(f'[hmc] trajectory {it}: epochs min {int(status[0].min())} max {int(status[0].max())}, '
+                  f'accepted this round {int(status[1].sum())}/{status.shape[1]}', file=sys.stderr, flush=True)
+
     res = hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
-                     chunk=getattr(opt, 'score_chunk', None), log=None if quiet else log)
+                     epochs=int(getattr(opt, 'hmc_epochs', 60)), sampling=int(getattr(opt, 'hmc_sampling', 20)),
+                     chunk=getattr(opt, 'score_chunk', None), log=(progress if every else None) if quiet else log)
     return res.samples[0] if n == 1 else res.samples
 
 

@@ -33,3 +33,8 @@ opi = operators.build_operator('inpaint_random', 3, 256, dev)
 yi = torch.randn(B, opi.M, device=dev)
 ms = timeit(lambda: opi.data_term(x, yi, True))
 print(f'inpaint data term B={B}: {ms*1e3:.1f} us  {(2*T)/ms/1e6:.0f} GB/s (2T dense)')
+for deg, nbytes in (('cs4', None), ('sr_bicubic4', None), ('color', None), ('deblur_gauss', None)):
+    o = operators.build_operator(deg, 3, 256, dev)
+    yy = torch.randn(B, o.M, device=dev)
+    ms = timeit(lambda: o.data_term(x, yy, True), 10)
+    print(f'{deg} data term B={B}: {ms*1e3:.1f} us  ({T/ms/1e6:.0f} GB/s per T moved)')
