@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   // Synchronous staging: with 3-4 blocks resident per CU the other blocks' MFMAs cover the global-load
-  // latency; register prefetch and LDS double buffering measured 5-10 % SLOWER here (scratch/gemm_bench.hip:
+  // latency; register prefetch and LDS double buffering measured 5-10 % SLOWER here (tools/gemm_bench.hip:
   // 57 us vs 61-69 us per 192-image product), because they cost registers and a second barrier.
   for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll

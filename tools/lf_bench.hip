@@ -1,5 +1,5 @@
 // Standalone A/B harness for the fused leapfrog update (not part of the product).
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off scratch/lf_bench.hip -o /tmp/lf_bench && /tmp/lf_bench
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/lf_bench.hip -o /tmp/lf_bench && /tmp/lf_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -2,7 +2,7 @@
 # rocprofv3 passes for the round-1 profile (run on the GPU box from the repo root)
 set -x
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/prof_r01b
+OUT=$PWD/gpurun_out/prof_r${ROUND:-01}
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > $OUT/e2e_bench.json 2> $OUT/e2e.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kern -- python3 bench.py --kernel-only --no-cpu-baseline > $OUT/kern_bench.json 2> $OUT/kern.err
