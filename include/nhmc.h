@@ -253,6 +253,31 @@ int nhmc_schedule_end_latent(const int32_t* accept, int32_t* rejected, double* t
                              double sigma_y_on_accept, int final_phase, int n_chains,
                              nhmc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Diagonal-mass variant (hmc_test_conditioning)     main_sampling.py:776-894
+ * nhmc_leapfrog_mass: the fused update with a per-element mass (inv_m = 1/M, std_m = sqrt(M), [n_chains][n_elem]):
+ *   FIRST: p = z*std_m (z: raw N(0,1) draw, :819); partials Sx = sum x^2, Sp = sum inv_m p^2 (:824);
+ *          p -= (eps/2) G; x += (eps p) inv_m (:834)
+ *   MID  : p -= eps G (:841); [Welford]; x += (eps p) inv_m
+ *   LAST : p -= eps G; p += (eps/2) G (:849); [Welford]; partials of the outputs (:852)
+ *   [Welford] (:843-847), for chains with welford_on: delta = x - mean; mean += delta/(l+1); M2 += delta (x - mean),
+ *   l = 0-based leapfrog index; at l = 0 mean and M2 are taken as zero (not read).  H = nhmc_hamiltonian with m_inv = 1.
+ * nhmc_mass_from_variance (:857-870): variance = M2/(L-1); ascending sort per chain; M = exp(2 rank/(N-1) - 1);
+ *   writes inv_m, std_m of the chains whose flag is set.  ws: nhmc_mass_sort_ws_bytes(n_chains, n_elem) bytes.
+ * nhmc_schedule_begin_mass (:808-816): sigma_table[e], e = 0..epochs, are the host-evaluated sigma_y values;
+ *   active = epoch < burn+epochs+4*sampling; welford_on = active && (epoch-burn) > epochs/3.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_leapfrog_mass(int mode, float* x, float* p, const float* z, const float* g, const float* g2,
+                       const float* inv_m, const float* std_m, const double* eps, const double* sigma_y,
+                       const int32_t* welford_on, float* mean, float* m2, int l, int n_chains,
+                       int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
+size_t nhmc_mass_sort_ws_bytes(int n_chains, int64_t n_elem);
+int nhmc_mass_from_variance(const float* m2, int L, const int32_t* flags, float* inv_m, float* std_m,
+                            void* ws, size_t ws_bytes, int n_chains, int64_t n_elem, nhmc_stream_t stream);
+int nhmc_schedule_begin_mass(const int32_t* epoch, double* tau, double* eps, double* sigma_y, double* eps_eff,
+                             int32_t* active, int32_t* welford_on, const double* sigma_table, int burn, int epochs,
+                             int sampling, int n_chains, nhmc_stream_t stream);
+
 /* PSNR of clamp((xt+1)/2,0,1) against clamp((x_orig+1)/2,0,1)   main_sampling.py:738-739
  * ws: double[n_chains][nhmc_data_tiles(n_elem)]. */
 int nhmc_psnr(const float* xt, const float* x_orig, float* psnr, double* ws,

@@ -53,6 +53,10 @@ SIGNATURES = {
     'nhmc_schedule_end': (I, [P, P, P, P, P, P, P, P, I, P]),
     'nhmc_latent_commit': (I, [P, P, P, I, I, P, P, P, P, P, I, I64, P]),
     'nhmc_schedule_end_latent': (I, [P, P, P, P, P, P, P, P, D, I, I, P]),
+    'nhmc_leapfrog_mass': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I64, P, P]),
+    'nhmc_mass_sort_ws_bytes': (SZ, [I, I64]),
+    'nhmc_mass_from_variance': (I, [P, I, P, P, P, P, SZ, I, I64, P]),
+    'nhmc_schedule_begin_mass': (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     'nhmc_psnr': (I, [P, P, P, P, I, I64, P]),
     'nhmc_randn_philox': (I, [P, U64, U32, U32, F, I, I64, P]),
     'nhmc_uniform_philox': (I, [P, U64, U32, U32, I, P]),

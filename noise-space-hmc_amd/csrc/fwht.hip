@@ -152,11 +152,109 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
   }
 }
 
+// ---- pass B, d = 256 fast path ---------------------------------------------------------------------------
+// Panel = 256 rows x 64 columns (256-byte row segments).  Thread (rg = t/16, cg = t%16) owns one float4 column
+// group and 16 rows: first the 16 CONSECUTIVE rows rg*16 + m (stages h = 1,2,4,8 in registers), one exchange through
+// LDS, then the 16 STRIDED rows rg + 16 m (stages h = 16..128 in registers) -- ascending h as in the reference, one
+// LDS write + read of the panel instead of eight.
+template <int EPI>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __restrict__ in, float* __restrict__ out,
+                                                             const float* __restrict__ y, float* __restrict__ y_out,
+                                                             const int32_t* __restrict__ kslot, const float* __restrict__ xt,
+                                                             double* __restrict__ loss_ws, int channels, int64_t m,
+                                                             int apply_clip) {
+  constexpr int D = 256, PC = 64;
+  __shared__ nhmc_v4f tile[D * PC / 4];                               // [row][16 column groups]
+  const int64_t plane = blockIdx.y;
+  const int c0 = blockIdx.x * PC;
+  const int c = (int)(plane % channels);
+  const int64_t chain = plane / channels;
+  const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
+  const float* __restrict__ src = in + plane * (int64_t)D * D + c0 + cg * 4;
+  nhmc_v4f v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const nhmc_v4f*>(&src[(int64_t)(rg * 16 + k) * D]);
+#pragma unroll
+  for (int h = 1; h < 16; h <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if ((k & h) == 0) {
+        const nhmc_v4f a = v[k], b = v[k + h];
+        v[k] = a + b;
+        v[k + h] = a - b;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tile[(rg * 16 + k) * (PC / 4) + cg] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = tile[(rg + 16 * k) * (PC / 4) + cg];
+#pragma unroll
+  for (int h = 1; h < 16; h <<= 1) {                                  // row stride 16*h
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if ((k & h) == 0) {
+        const nhmc_v4f a = v[k], b = v[k + h];
+        v[k] = a + b;
+        v[k + h] = a - b;
+      }
+    }
+  }
+  const float scale = 1.0f / 256.0f;
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = rg + 16 * k;
+    const int64_t q = (int64_t)i * D + c0 + cg * 4;
+    const int64_t off = plane * (int64_t)D * D + q;
+    nhmc_v4f val = v[k] * scale;
+    if (EPI == EPI_STORE) {
+      *reinterpret_cast<nhmc_v4f*>(&out[off]) = val;
+    } else if (EPI == EPI_SCATTER) {
+      const int4 ks = *reinterpret_cast<const int4*>(&kslot[q]);
+      if (ks.x >= 0) y_out[chain * m + (int64_t)ks.x * channels + c] = val.x;
+      if (ks.y >= 0) y_out[chain * m + (int64_t)ks.y * channels + c] = val.y;
+      if (ks.z >= 0) y_out[chain * m + (int64_t)ks.z * channels + c] = val.z;
+      if (ks.w >= 0) y_out[chain * m + (int64_t)ks.w * channels + c] = val.w;
+    } else if (EPI == EPI_RESID) {
+      const int4 ks = *reinterpret_cast<const int4*>(&kslot[q]);
+      const int kk[4] = {ks.x, ks.y, ks.z, ks.w};
+      nhmc_v4f r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float re = 0.0f;
+        if (kk[e] >= 0) { re = y[chain * m + (int64_t)kk[e] * channels + c] - val[e]; acc += re * re; }
+        r[e] = re;
+      }
+      *reinterpret_cast<nhmc_v4f*>(&out[off]) = r;
+    } else {
+      nhmc_v4f gq = -(2.0f * val);
+      if (apply_clip) {
+        const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&xt[off]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[e] = gq[e] * nhmc_in1(xv[e]);
+      }
+      *reinterpret_cast<nhmc_v4f*>(&out[off]) = gq;
+    }
+  }
+  if (EPI == EPI_RESID) {
+    __shared__ double red[4];
+    double sacc[1] = {(double)acc};
+    nhmc_block_sum<1>(sacc, red);
+    if (threadIdx.x == 0) loss_ws[plane * gridDim.x + blockIdx.x] = sacc[0];
+  }
+}
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 bool bad(int n_chains, int channels, int dim) {
   return n_chains <= 0 || channels <= 0 || !pow2(dim) || dim < 16 || dim > 1024 || (int64_t)n_chains * channels > 65535;
 }
-int panel_cols(int dim) { int pc = 8192 / dim; return pc > dim ? dim : (pc < 8 ? 8 : pc); }   // d*pc*4 B <= 32 KiB (d <= 1024)
+int panel_cols(int dim) {                         // d = 256: the register fast path (64 columns); else d*pc*4 B <= 32 KiB
+  if (dim == 256) return 64;
+  int pc = 8192 / dim;
+  return pc > dim ? dim : (pc < 8 ? 8 : pc);
+}
 
 template <int PRO>
 int rows(const float* in, const float* y, const int32_t* kslot, float* out, int n_chains, int channels, int dim,
@@ -178,6 +276,10 @@ int cols(const float* in, float* out, const float* y, float* y_out, const int32_
          int n_chains, int channels, int dim, int64_t m, int apply_clip, hipStream_t st) {
   const int pc = panel_cols(dim);
   dim3 grid((unsigned)(dim / pc), (unsigned)(n_chains * channels)), block(NHMC_BLOCK);
+  if (dim == 256) {
+    NHMC_LAUNCH((k_fwht_cols256<EPI>), grid, block, 0, st, in, out, y, y_out, kslot, xt, ws, channels, m, apply_clip);
+    return nhmc_launch_status();
+  }
   NHMC_LAUNCH((k_fwht_cols<EPI>), grid, block, (size_t)dim * pc * sizeof(float), st, in, out, y, y_out, kslot, xt, ws,
               dim, pc, channels, m, apply_clip);
   return nhmc_launch_status();

@@ -399,6 +399,41 @@ def schedule_end_latent(accept, st, sigma_y_on_accept, final_phase):
     _lib.check(rc, 'nhmc_schedule_end_latent')
 
 
+def leapfrog_mass(mode, x, p, g, inv_m, eps, sigma_y, sums_ws=None, g2=None, z=None, std_m=None, welford_on=None,
+                  mean=None, m2=None, l=0):
+    lib = _lib.load()
+    B, N = _chains_elems(x)
+    rc = lib.nhmc_leapfrog_mass(mode, _p(x, torch.float32, 'x'), _p(p, torch.float32, 'p'), _p(z, torch.float32, 'z'),
+                                _p(g, torch.float32, 'g'), _p(g2, torch.float32, 'g2'), _p(inv_m, torch.float32, 'inv_m'),
+                                _p(std_m, torch.float32, 'std_m'), _p(_f64(eps, B, x.device)), _p(_f64(sigma_y, B, x.device)),
+                                _p(welford_on, torch.int32), _p(mean, torch.float32), _p(m2, torch.float32), int(l), B, N,
+                                _p(sums_ws, torch.float64), _stream())
+    _lib.check(rc, 'nhmc_leapfrog_mass')
+
+
+def mass_from_variance(m2, L, flags, inv_m, std_m, ws=None):
+    lib = _lib.load()
+    B, N = _chains_elems(m2)
+    need = lib.nhmc_mass_sort_ws_bytes(B, N)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=m2.device)
+    rc = lib.nhmc_mass_from_variance(_p(m2, torch.float32, 'm2'), int(L), _p(flags, torch.int32), _p(inv_m, torch.float32),
+                                     _p(std_m, torch.float32), _p(ws), ws.numel(), B, N, _stream())
+    _lib.check(rc, 'nhmc_mass_from_variance')
+    return ws
+
+
+def schedule_begin_mass(state, sigma_table, burn, epochs, sampling):
+    lib = _lib.load()
+    B = state['epoch'].numel()
+    rc = lib.nhmc_schedule_begin_mass(_p(state['epoch'], torch.int32), _p(state['tau'], torch.float64),
+                                      _p(state['eps'], torch.float64), _p(state['sigma_y'], torch.float64),
+                                      _p(state['eps_eff'], torch.float64), _p(state['active'], torch.int32),
+                                      _p(state['welford_on'], torch.int32), _p(sigma_table, torch.float64), burn, epochs,
+                                      sampling, B, _stream())
+    _lib.check(rc, 'nhmc_schedule_begin_mass')
+
+
 def psnr(xt, x_orig):
     lib = _lib.load()
     B, N = _chains_elems(xt)

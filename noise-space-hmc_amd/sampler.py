@@ -306,6 +306,81 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
 
 
 # --------------------------------------------------------------------------------------------- #
+# diagonal-mass variant
+# --------------------------------------------------------------------------------------------- #
+def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, burn=5, epochs=40,
+                    sampling=10, chunk=None, max_iters=None, collect_trace=False):
+    """Per-chain form of `hmc_test_conditioning` (main_sampling.py:776-894): HMC with a diagonal mass rebuilt from
+    the rank transform of each accepted trajectory's position variance.  Returns SimpleNamespace(samples
+    [B, 4*sampling-sampling... = total-(epochs+sampling), C, H, W], x, epoch, n_accept, n_reject, iters, trace)."""
+    device = x.device
+    B, N = x.shape[0], x[0].numel()
+    tau, epsilon = float(opt.tau), float(opt.epsilon)
+    sigma_0 = float(opt.sigma_0)
+    L = max(1, math.floor(tau / epsilon))
+    total = burn + epochs + 4 * sampling
+    n_keep = total - (epochs + sampling)
+    noise = noise or TorchNoise()
+    if not hasattr(H_funcs, 'data_term'):
+        raise TypeError('H_funcs must be an nhmc.operators operator (needs the fused data_term)')
+    score = algo.score if hasattr(algo, 'score') else algo.model
+    engine = LeapfrogEngine(score, H_funcs, b, seq, seq_next, device, chunk=chunk)
+    sig = [sigma_0 + 0.9 if e < burn else sigma_0 + 0.9 * (1 - (e - burn) / epochs) ** 3 for e in range(epochs)] + [sigma_0]
+    sigma_table = torch.tensor(sig, dtype=torch.float64, device=device)                      # :808-813 in Python floats
+    x = x.detach().clone().contiguous()
+    y_0 = y_0.contiguous()
+    st = ChainState(B, tau, epsilon, device)
+    st.t['welford_on'] = torch.zeros(B, dtype=torch.int32, device=device)
+    inv_m, std_m = torch.ones_like(x), torch.ones_like(x)
+    mean, m2 = torch.zeros_like(x), torch.zeros_like(x)
+    samples = torch.zeros((B, n_keep) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
+    ws, sort_ws = K.leapfrog_ws(B, N, device), None
+    trace = [] if collect_trace else None
+    it = 0
+    while True:
+        K.schedule_begin_mass(st, sigma_table, burn, epochs, sampling)
+        z = noise.momentum(it, x, 1.0)
+        eps, sy, won = st['eps_eff'], st['sigma_y'], st['welford_on']
+        xt, loss, ga, gb = engine.decode_and_grad(x, y_0)
+        x_prop, p = x.clone(), torch.empty_like(x)
+        m2.zero_()                                      # chains without Welford keep M2 = 0 (the reference's zeros, :802)
+        K.leapfrog_mass(K.LF_FIRST, x_prop, p, ga, inv_m, eps, sy, ws, g2=gb, z=z, std_m=std_m)
+        H0 = K.hamiltonian(ws, N, loss, sy, 1.0)
+        for l in range(L):
+            xt, loss, ga, gb = engine.decode_and_grad(x_prop, y_0)
+            K.leapfrog_mass(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, p, ga, inv_m, eps, sy, ws, g2=gb,
+                            welford_on=won, mean=mean, m2=m2, l=l)
+        H1 = K.hamiltonian(ws, N, loss, sy, 1.0)
+        u = noise.uniform(it, B, device)
+        accept, dH = K.metropolis(H0, H1, u, st['active'])
+        # mass rebuild for accepted chains past epochs//3 (pre-increment epoch, :857)
+        flags = (accept * (st['epoch'] > epochs // 3).int()).contiguous()
+        sort_ws = K.mass_from_variance(m2, L, flags, inv_m, std_m, sort_ws)
+        K.accept_commit(accept, st['epoch'], x, x_prop, xt, samples, epochs + sampling - n_keep, n_keep)
+        epoch_before = st['epoch'].clone() if collect_trace else None
+        K.schedule_end(accept, st)
+        it += 1
+        status = torch.stack([st['epoch'], accept]).cpu()
+        if collect_trace:
+            trace.append(dict(dH=dH.cpu(), accept=status[1].clone(), epoch=epoch_before.cpu()))
+        if int(status[0].min()) >= total or (max_iters is not None and it >= max_iters):
+            break
+    return SimpleNamespace(samples=samples, x=x, epoch=st['epoch'], n_accept=st['n_accept'], n_reject=st['n_reject'],
+                           iters=it, trace=trace, L=L)
+
+
+def hmc_test_conditioning(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
+    """Reference entry point (main_sampling.py:776): [35, C, H, W] at n = 1, [n, 35, C, H, W] otherwise."""
+    noise = getattr(opt, 'noise_source', None)
+    if noise is None:
+        seed = getattr(opt, 'philox_seed', None)
+        noise = PhiloxNoise(seed, getattr(opt, 'chain_id0', 0)) if seed is not None else TorchNoise()
+    res = hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
+                          chunk=getattr(opt, 'score_chunk', None))
+    return res.samples[0] if n == 1 else res.samples
+
+
+# --------------------------------------------------------------------------------------------- #
 # latent variant
 # --------------------------------------------------------------------------------------------- #
 def hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, epochs=50, sampling=10,
