@@ -25,7 +25,7 @@ def test_leapfrog_mass_kernel_matches_reference_ops():
     M = torch.exp(torch.rand(shape, generator=g_) * 2 - 1)
     std, inv = torch.sqrt(M), 1.0 / M
     eps, sig = 0.05, 0.9
-    ef, eh, kf = np.float32(eps), np.float32(eps / 2), np.float32(1 / (2 * sig ** 2))
+    ef, eh, kf = eps, eps / 2, 1 / (2 * sig ** 2)          # python floats: torch rounds them to fp32 per op, as in the reference
     # FIRST
     p = z * std
     Sx, Sp = (x.double() ** 2).sum((1, 2, 3)), (inv * p ** 2).double().sum((1, 2, 3))
