@@ -122,10 +122,12 @@ def hot_path_only(device, prob, B, steps):
         for s in range(3):
             ins.append(cur)
             cur = K.ddim_mix_fwd(cur, e, at[s], atn[s], final_clip=(s == 2))['xt_next']
-        loss, g = op.data_term(cur, y, apply_clip=False)
         g2 = None
         for s in (2, 1, 0):
-            g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], final_clip=(s == 2), gout2=g2)
+            if s == 2:                                              # data term fused into the last-step VJP
+                loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y)
+            else:
+                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], gout2=g2)
             g2 = gs                                                 # stands in for the score's input-gradient
         K.leapfrog_fused(K.LF_MID, x, p, g, eps, sig, 1.0, g2=g2)
     for _ in range(3):
@@ -137,7 +139,7 @@ def hot_path_only(device, prob, B, steps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return dict(value=B * steps / dt, unit='chain-steps/s', ms_per_step=1e3 * dt / steps, steps=steps,
-                note='score output resident (no U-Net); 3 mix fwd + data term + 3 mix VJP + fused update')
+                note='score output resident (no U-Net); 3 mix fwd + (data term + last VJP fused) + 2 mix VJP + fused update')
 
 
 def host_cores():

@@ -103,6 +103,14 @@ int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* g_x0, 
                       float* g_xt, float* g_e,
                       int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
 
+/* a11 + a12/a13 fused: VJP of the LAST DDIM step (final clip included) with the inpainting data term computed on the
+ * fly from (xt, e): r = y[slot] - clip(xt_next), loss partials (nhmc_leapfrog_tiles(n_elem) per chain), gin = -2 r.
+ * Replaces nhmc_data_inpaint + nhmc_ddim_mix_bwd(final_clip = 1) for deg = inpaint_* (same bits, -3T of traffic). */
+int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, const float* at,
+                              const float* at_next, const float* y, const int32_t* slot, int64_t m,
+                              float* g_xt, float* g_e, double* loss_ws, int n_chains, int channels,
+                              int64_t hw, nhmc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a12-a14  Data term: loss_b = sum (y_b - H clip(xt_b))^2 and d loss / d xt
  *                                          main_sampling.py:693-695,709-711

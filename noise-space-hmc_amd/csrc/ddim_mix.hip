@@ -141,6 +141,65 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
   }
 }
 
+// Last DDIM step VJP fused with the inpainting data term (primary BASELINE config): the clipped decode
+// xt_next = clip(c3*clip(u) + c4*e) is recomputed in registers (bit-identical to k_mix_fwd), the residual
+// r = y[slot] - xt_next and the upstream gradient gin = -2 r are formed on the fly, so the separate data-term pass
+// (R xt_next, W g) and this kernel's read of g disappear: -3T per leapfrog step and one launch.
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
+    const float4* __restrict__ xt, const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
+    const float* __restrict__ at_next, const float* __restrict__ y, const int4* __restrict__ slot, int64_t m,
+    float4* __restrict__ g_xt, float4* __restrict__ g_e, double* __restrict__ loss_ws, int64_t n4) {
+  const int chain = blockIdx.y;
+  const Coef k = coef(at, at_next, chain);
+  const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
+  const float* yb = y + (int64_t)chain * m;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    const float4 xv = nhmc_ldnt(&xt[base + q]), ev = nhmc_ldnt(&e[ebase + q]);
+    const int4 sv = slot[q];
+    const float* xe = reinterpret_cast<const float*>(&xv);
+    const float* ee = reinterpret_cast<const float*>(&ev);
+    const int* se = reinterpret_cast<const int*>(&sv);
+    float4 ox, oe;
+    float* gx = reinterpret_cast<float*>(&ox);
+    float* gee = reinterpret_cast<float*>(&oe);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float u = (xe[c] - ee[c] * k.c1) / k.c2;
+      const float pre = k.c3 * nhmc_clip1(u) + k.c4 * ee[c];    // decode before the final clip
+      float gin = 0.0f;
+      if (se[c] >= 0) {
+        const float r = yb[se[c]] - nhmc_clip1(pre);
+        acc += r * r;
+        gin = -(2.0f * r);
+      }
+      gin = gin * nhmc_in1(pre);                                 // final clip mask
+      const float gu = ((gin * k.c3) * nhmc_in1(u)) / k.c2;
+      gx[c] = gu;
+      gee[c] = k.c4 * gin + (-gu) * k.c1;
+    }
+    nhmc_stnt(&g_xt[base + q], ox);
+    nhmc_stnt(&g_e[ebase + q], oe);
+  }
+  const int64_t extra = e_stride4 - n4;
+  if (extra > 0) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+      const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+      if (q < extra) nhmc_stnt(&g_e[ebase + n4 + q], z);
+    }
+  }
+  __shared__ double red[4];
+  double v[1] = {(double)acc};
+  nhmc_block_sum<1>(v, red);
+  if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
+}
+
 bool bad_shape(int n_chains, int channels, int64_t hw, int e_channels) {
   return n_chains <= 0 || n_chains > 65535 || channels <= 0 || hw <= 0 ||
          (e_channels != channels && e_channels != 2 * channels);
@@ -211,5 +270,23 @@ extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const fl
   else if (gout2) NHMC_BWD(true, false);
   else NHMC_BWD(false, false);
 #undef NHMC_BWD
+  return nhmc_launch_status();
+}
+
+// Last-step VJP fused with the inpainting data term; loss partials: nhmc_leapfrog_tiles(n_elem) per chain.
+extern "C" int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, const float* at,
+                                         const float* at_next, const float* y, const int32_t* slot, int64_t m,
+                                         float* g_xt, float* g_e, double* loss_ws, int n_chains, int channels,
+                                         int64_t hw, nhmc_stream_t stream) {
+  if (!xt || !e || !at || !at_next || !y || !slot || !g_xt || !g_e || !loss_ws || m <= 0) return NHMC_ERR_ARG;
+  if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
+  const int64_t n_elem = (int64_t)channels * hw;
+  if ((n_elem & 3) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(slot) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(g_e))
+    return NHMC_ERR_ALIGN;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  NHMC_LAUNCH(k_mix_bwd_inpaint, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
+              (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)slot, m, (float4*)g_xt, (float4*)g_e, loss_ws,
+              n_elem / 4);
   return nhmc_launch_status();
 }

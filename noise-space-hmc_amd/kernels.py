@@ -106,8 +106,9 @@ def ddim_map_back(x0_t, add_up, at_next):
     lib = _lib.load()
     B, N = _chains_elems(x0_t)
     out = torch.empty_like(x0_t)
-    rc = lib.nhmc_ddim_map_back(_p(x0_t, torch.float32, 'x0_t'), _p(add_up, torch.float32, 'add_up'),
-                                _p(_alpha(at_next, B, x0_t.device)), _p(out), B, N, _stream())
+    an = _alpha(at_next, B, x0_t.device)                 # keep temporaries alive until after the launch call:
+    rc = lib.nhmc_ddim_map_back(_p(x0_t, torch.float32, 'x0_t'), _p(add_up, torch.float32, 'add_up'),   # a freed block
+                                _p(an), _p(out), B, N, _stream())                                          # can be re-issued
     _lib.check(rc, 'nhmc_ddim_map_back')
     return out
 
@@ -123,6 +124,21 @@ def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=No
                                int(final_clip), _p(g_xt), _p(g_e), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd')
     return g_xt, g_e
+
+
+def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot):
+    """Last-step VJP fused with the inpainting data term -> (loss [B] float64, g_xt, g_e)."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    g_xt, g_e = torch.empty_like(xt), torch.empty_like(e)
+    tiles = leapfrog_tiles(Cc * hw)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    rc = lib.nhmc_ddim_mix_bwd_inpaint(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                       _p(y, torch.float32, 'y'), _p(slot, torch.int32, 'slot'), y.shape[1], _p(g_xt),
+                                       _p(g_e), _p(ws), B, Cc, hw, _stream())
+    _lib.check(rc, 'nhmc_ddim_mix_bwd_inpaint')
+    return sum_partials(ws, tiles, B), g_xt, g_e
 
 
 # ---- a12-a15 --------------------------------------------------------------------------------
@@ -332,8 +348,9 @@ def hamiltonian(sums_ws, n_elem, loss, sigma_y, m_inv, want_terms=False):
     B = loss.numel()
     H = torch.empty(B, dtype=torch.float32, device=loss.device)
     terms = torch.empty(B, 3, dtype=torch.float64, device=loss.device) if want_terms else None
+    sy = _f64(sigma_y, B, loss.device)
     rc = lib.nhmc_hamiltonian(_p(sums_ws, torch.float64), leapfrog_tiles(n_elem), _p(loss, torch.float64, 'loss'),
-                              _p(_f64(sigma_y, B, loss.device)), float(m_inv), _p(H), _p(terms), B, _stream())
+                              _p(sy), float(m_inv), _p(H), _p(terms), B, _stream())
     _lib.check(rc, 'nhmc_hamiltonian')
     return (H, terms) if want_terms else H
 
@@ -403,9 +420,10 @@ def leapfrog_mass(mode, x, p, g, inv_m, eps, sigma_y, sums_ws=None, g2=None, z=N
                   mean=None, m2=None, l=0):
     lib = _lib.load()
     B, N = _chains_elems(x)
+    ep, sy = _f64(eps, B, x.device), _f64(sigma_y, B, x.device)          # two live tensors (never alias a freed block)
     rc = lib.nhmc_leapfrog_mass(mode, _p(x, torch.float32, 'x'), _p(p, torch.float32, 'p'), _p(z, torch.float32, 'z'),
                                 _p(g, torch.float32, 'g'), _p(g2, torch.float32, 'g2'), _p(inv_m, torch.float32, 'inv_m'),
-                                _p(std_m, torch.float32, 'std_m'), _p(_f64(eps, B, x.device)), _p(_f64(sigma_y, B, x.device)),
+                                _p(std_m, torch.float32, 'std_m'), _p(ep), _p(sy),
                                 _p(welford_on, torch.int32), _p(mean, torch.float32), _p(m2, torch.float32), int(l), B, N,
                                 _p(sums_ws, torch.float64), _stream())
     _lib.check(rc, 'nhmc_leapfrog_mass')

@@ -78,6 +78,10 @@ class Inpainting(H_functions):
     def data_term(self, xt, y, apply_clip=True):
         return K.data_inpaint(xt, y, self.slot, apply_clip)
 
+    def fused_last_vjp(self, xt_in, e, at, at_next, y):
+        """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
+        return K.ddim_mix_bwd_inpaint(xt_in, e, at, at_next, y, self.slot)
+
 
 class SuperResolution(H_functions):
     """obs_functions/Hfuncs.py:180-234: r x r block mean, H^T = broadcast / r^2, H^+ = broadcast."""

@@ -100,6 +100,7 @@ class LeapfrogEngine:
         map applied to the clipped decode before the operator (the latent variant's first-stage decoder, :651)."""
         self.score, self.operator, self.device, self.chunk = score, operator, device, chunk
         self.image_map = image_map
+        self.fuse_last = True                  # use operator.fused_last_vjp when it exists (inpainting)
         steps = list(zip(reversed(seq), reversed(seq_next)))
         from .schedule import alpha_bar_table
         table = alpha_table.to(device).float() if alpha_table is not None else alpha_bar_table(b)
@@ -140,8 +141,11 @@ class LeapfrogEngine:
             ins.append((leaf, e_c))
             outs.append(e)
         xt_out.copy_(cur)
+        fused = self.image_map is None and self.fuse_last and hasattr(self.operator, 'fused_last_vjp')
         # the final clip is applied by the last mix; its mask is re-derived inside the last mix backward
-        if self.image_map is None:
+        if fused:
+            l = g = None
+        elif self.image_map is None:
             l, g = self.operator.data_term(cur, y, apply_clip=False)
         else:
             zleaf = cur.detach().requires_grad_(True)
@@ -150,12 +154,18 @@ class LeapfrogEngine:
             l, g_img = self.operator.data_term(img.detach().contiguous(), y, apply_clip=False)
             (g,) = torch.autograd.grad(img, zleaf, g_img)
             g = g.contiguous()
-        loss_out.copy_(l)
+        if not fused:
+            loss_out.copy_(l)
         g2 = None
         for s in reversed(range(S)):
             leaf, e_c = ins[s]
-            g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
-                                           final_clip=(s == S - 1), gout2=g2)
+            if fused and s == S - 1:                  # data term + last-step VJP in one kernel
+                l, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, self.at[s].expand(n),
+                                                                self.at_next[s].expand(n), y)
+                loss_out.copy_(l)
+            else:
+                g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
+                                               final_clip=(s == S - 1), gout2=g2)
             (g_score,) = torch.autograd.grad(outs[s], leaf, g_e)
             outs[s] = None
             g, g2 = g_direct, g_score.contiguous()
