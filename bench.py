@@ -259,6 +259,8 @@ def main():
         }
         print(json.dumps(line), flush=True)
     sharding.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

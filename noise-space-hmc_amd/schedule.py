@@ -33,11 +33,12 @@ _tables = {}
 
 
 def alpha_bar_table(b):
-    """fp32 table on b's device, entry k = alpha-bar at t = k-1 (entry 0 = 1)."""
-    key = (b.data_ptr(), b.device, b.numel(), getattr(b, '_version', 0))
+    """fp32 table on b's device, entry k = alpha-bar at t = k-1 (entry 0 = 1).  Cached by the betas' VALUES (the
+    host copy is needed for the product anyway), so a recycled device address can never return a stale table."""
+    host = b.detach().float().cpu()
+    key = (str(b.device), host.numpy().tobytes())
     hit = _tables.get(key)
     if hit is None:
-        host = b.detach().float().cpu()
         table = (1 - torch.cat([torch.zeros(1), host])).cumprod(dim=0)
         hit = table.to(b.device)
         if len(_tables) > 16:
