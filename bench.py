@@ -51,16 +51,18 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-only', action='store_true', help='skip the end-to-end steps (profiling the HIP kernels)')
     ap.add_argument('--roofline-launches', type=int, default=200)
+    ap.add_argument('--deg', default='inpaint_random',
+                    help='degradation: inpaint_random (the BASELINE metric), sr4 (configs[2]), deblur_aniso (configs[3]), ...')
     ap.add_argument('--rehearse-shared-gpu', action='store_true',
                     help='rehearsal only: all ranks use cuda:0 over gloo (checks the N>1 control flow on a 1-GPU box)')
     return ap.parse_args()
 
 
-def build_problem(device, B, chain_id0, seed=5678):
+def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random'):
     import nhmc.kernels as K
     from nhmc import operators, plugin, sampler, schedule, unet
     gen = torch.Generator().manual_seed(seed)
-    op = operators.build_operator('inpaint_random', CH, DIM, device, generator=gen)
+    op = operators.build_operator(deg, CH, DIM, device, generator=gen)
     torch.manual_seed(seed)
     model = unet.create_model(**unet.FFHQ_CONFIG).to(device).eval().requires_grad_(False)
     algo = plugin.HMC(model, op, 2 * SIGMA0_CLI)
@@ -124,8 +126,11 @@ def hot_path_only(device, prob, B, steps):
             cur = K.ddim_mix_fwd(cur, e, at[s], atn[s], final_clip=(s == 2))['xt_next']
         g2 = None
         for s in (2, 1, 0):
-            if s == 2:                                              # data term fused into the last-step VJP
+            if s == 2 and hasattr(op, 'fused_last_vjp'):            # data term fused into the last-step VJP
                 loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y)
+            elif s == 2:
+                loss, g = op.data_term(cur, y, apply_clip=False)
+                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], final_clip=True)
             else:
                 g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], gout2=g2)
             g2 = gs                                                 # stands in for the score's input-gradient
@@ -195,7 +200,7 @@ def main():
     device = torch.device('cuda', local_rank)
     B = args.batch
     lo = rank * B                                                      # global chain ids of this rank (weak scaling)
-    prob = build_problem(device, B, lo)
+    prob = build_problem(device, B, lo, deg=args.deg)
     eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device,
                                  chunk=args.chunk)
     x, p, y = prob['x'], prob['p'], prob['y']
@@ -246,12 +251,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
         line = {
-            'metric': 'HMC leapfrog chain-steps/sec (256x256x3 FFHQ inpaint_random, U-Net score in the loop)',
+            'metric': f'HMC leapfrog chain-steps/sec (256x256x3 FFHQ {args.deg}, U-Net score in the loop)',
             'value': None if value is None else round(value, 3), 'unit': 'chain-steps/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': None if ms_per_step is None else round(ms_per_step, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: FFHQ 256x256 inpaint_random sigma_0=0.05 tau=1.0 eps=0.05 '
+            'config': {'workload': ('BASELINE configs[1]' if args.deg == 'inpaint_random' else 'BASELINE configs[1] with another degradation') +
+                                   f': FFHQ 256x256 {args.deg} sigma_0=0.05 tau=1.0 eps=0.05 '
                                    'timesteps=3, 64 chains per GPU, FFHQ U-Net architecture random-init fp32',
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
