@@ -233,7 +233,23 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         value = world * B * args.steps / dt
 
-    roof = hot = cpu = None
+    roof = hot = cpu = single = None
+    if rank == 0 and not args.kernel_only:
+        # the reference's own operating point: ONE chain (its hmc() is batch-1 only); BASELINE.md derives
+        # ~3.2 leapfrog steps/s for it from the authors' logs (unstated NVIDIA GPU)
+        x1, p1, y1 = x[:1].clone(), p[:1].clone(), y[:1].contiguous()
+        e1, s1 = eps[:1].contiguous(), sig[:1].contiguous()
+        for _ in range(2):
+            _, _, ga, gb = eng.decode_and_grad(x1, y1)
+            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _, _, ga, gb = eng.decode_and_grad(x1, y1)
+            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+        torch.cuda.synchronize()
+        single = dict(value=round(5 / (time.perf_counter() - t0), 2), unit='leapfrog steps/s', chains=1,
+                      reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
     if rank == 0:
         roof = leapfrog_roofline(device, B, args.roofline_launches)
         hot = hot_path_only(device, prob, B, 20)
@@ -261,7 +277,7 @@ def main():
                                    'timesteps=3, 64 chains per GPU, FFHQ U-Net architecture random-init fp32',
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
-            'roofline': roofline, 'hot_path_only': hot, 'cpu_baseline': cpu,
+            'roofline': roofline, 'hot_path_only': hot, 'single_chain': single, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     sharding.barrier()
