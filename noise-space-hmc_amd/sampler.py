@@ -101,6 +101,7 @@ class LeapfrogEngine:
         self.score, self.operator, self.device, self.chunk = score, operator, device, chunk
         self.image_map = image_map
         self.fuse_last = True                  # use operator.fused_last_vjp when it exists (inpainting)
+        self._graphs = {}                      # (n, shape of y) -> captured decode+gradient of one chunk
         steps = list(zip(reversed(seq), reversed(seq_next)))
         from .schedule import alpha_bar_table
         table = alpha_table.to(device).float() if alpha_table is not None else alpha_bar_table(b)
@@ -114,16 +115,45 @@ class LeapfrogEngine:
         c = self.chunk or B
         return [(s, min(B, s + c)) for s in range(0, B, c)]
 
-    def decode_and_grad(self, x, y):
+    def decode_and_grad(self, x, y, graph=False):
         """-> xt [B,C,H,W] (clipped decode), loss [B] fp64, (g_direct, g_score): the two pieces of
-        d(sum_b loss_b)/dx, summed later inside the consuming kernel."""
+        d(sum_b loss_b)/dx, summed later inside the consuming kernel.
+
+        graph=True replays one hipGraph per chunk (score network forward + input-gradient included) instead of
+        launching its ~10^3 kernels from Python: same kernels, same results; pays off when a chunk is small
+        (the reference's one-chain operating point), where the step is launch-bound."""
         B = x.shape[0]
         xt_out = torch.empty_like(x)
         ga, gb = torch.empty_like(x), torch.empty_like(x)
         loss = torch.empty(B, dtype=torch.float64, device=x.device)
         for lo, hi in self._chunks(B):
-            self._decode_and_grad_chunk(x[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi], ga[lo:hi], gb[lo:hi])
+            run = self._graphed_chunk if graph else self._decode_and_grad_chunk
+            run(x[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi], ga[lo:hi], gb[lo:hi])
         return xt_out, loss, ga, gb
+
+    def _graphed_chunk(self, x, y, xt_out, loss_out, ga_out, gb_out):
+        key = (tuple(x.shape), tuple(y.shape))
+        rec = self._graphs.get(key)
+        if rec is None:
+            sx, sy = x.clone(), y.clone()
+            outs = (torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float64, device=x.device),
+                    torch.empty_like(x), torch.empty_like(x))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up: solver selection, allocator pools
+                for _ in range(2):
+                    self._decode_and_grad_chunk(sx, sy, *outs)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_and_grad_chunk(sx, sy, *outs)
+            rec = self._graphs[key] = (g, sx, sy, outs)
+        g, sx, sy, outs = rec
+        sx.copy_(x)
+        sy.copy_(y)
+        g.replay()
+        for dst, src in zip((xt_out, loss_out, ga_out, gb_out), outs):
+            dst.copy_(src)
 
     def _decode_and_grad_chunk(self, x, y, xt_out, loss_out, ga_out, gb_out):
         n = x.shape[0]
