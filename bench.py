@@ -248,7 +248,22 @@ def main():
             _, _, ga, gb = eng.decode_and_grad(x1, y1)
             K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
         torch.cuda.synchronize()
-        single = dict(value=round(5 / (time.perf_counter() - t0), 2), unit='leapfrog steps/s', chains=1,
+        eager = 5 / (time.perf_counter() - t0)
+        graphed = None
+        try:                                                 # same step replayed as one hipGraph per decode+gradient
+            for _ in range(2):
+                _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
+                K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
+                K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+            torch.cuda.synchronize()
+            graphed = round(5 / (time.perf_counter() - t0), 2)
+        except RuntimeError as exc:                          # capture support is the framework's, not ours: report, go on
+            graphed = f'capture failed: {str(exc)[:80]}'
+        single = dict(value=round(eager, 2), value_hipgraph=graphed, unit='leapfrog steps/s', chains=1,
                       reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
     if rank == 0:
         roof = leapfrog_roofline(device, B, args.roofline_launches)

@@ -53,6 +53,8 @@ def get_parser():
     p.add_argument('--synthetic', type=int, default=0, help='use this many synthetic images')
     p.add_argument('--philox', action='store_true', help='counter-based, shard-invariant noise')
     p.add_argument('--save_images', action='store_true')
+    p.add_argument('--graph', dest='use_graph', action='store_true',
+                   help='replay each decode+gradient chunk as a hipGraph (helps single-chain runs: ~1.2x)')
     p.add_argument('--hmc_epochs', type=int, default=60, help='annealing epochs (reference: 60, main_sampling.py:665)')
     p.add_argument('--hmc_sampling', type=int, default=20, help='collected samples (reference: 20, :666)')
     return p

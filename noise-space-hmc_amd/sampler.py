@@ -234,27 +234,27 @@ class ChainState:
         return self.t.get(k, default)
 
 
-def run_trajectory(engine, x, p, y, state, m, L, ws=None):
+def run_trajectory(engine, x, p, y, state, m, L, ws=None, graph=False):
     """One outer iteration (main_sampling.py:693-718) for all chains.  x is NOT modified.
     -> dict(x_prop, p, xt, loss, H0, H1)"""
     B, N = x.shape[0], x[0].numel()
     m_inv = m ** (-1)
     eps, sig = state['eps_eff'], state['sigma_y']
     ws = ws if ws is not None else K.leapfrog_ws(B, N, x.device)
-    xt, loss, ga, gb = engine.decode_and_grad(x, y)
+    xt, loss, ga, gb = engine.decode_and_grad(x, y, graph=graph)
     x_prop = x.clone()
     K.leapfrog_fused(K.LF_FIRST, x_prop, p, ga, eps, sig, m_inv, ws, g2=gb)
     H0 = K.hamiltonian(ws, N, loss, sig, m_inv)
     for l in range(L):
-        xt, loss, ga, gb = engine.decode_and_grad(x_prop, y)
+        xt, loss, ga, gb = engine.decode_and_grad(x_prop, y, graph=graph)
         K.leapfrog_fused(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, p, ga, eps, sig, m_inv, ws, g2=gb)
     H1 = K.hamiltonian(ws, N, loss, sig, m_inv)
     return dict(x_prop=x_prop, p=p, xt=xt, loss=loss, H0=H0, H1=H1)
 
 
 def hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, epochs=60, sampling=20,
-               chunk=None, max_iters=None, log=None, collect_trace=False):
-    """Per-chain HMC for B = x.shape[0] chains.  Returns a SimpleNamespace:
+               chunk=None, max_iters=None, log=None, collect_trace=False, graph=False):
+    """Per-chain HMC for B = x.shape[0] chains (graph=True: hipGraph replay of each decode+gradient chunk).  Returns a SimpleNamespace:
         samples [B, sampling, C, H, W]   accepted decodes of epochs epochs+sampling .. epochs+2*sampling-1
         x       [B, C, H, W]             final noise-space positions
         n_accept, n_reject, epoch [B]    int32
@@ -286,7 +286,7 @@ def hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noi
     while True:
         K.schedule_begin(state, sigma_0, epochs, sampling)
         p = noise.momentum(it, x, math.sqrt(m))
-        out = run_trajectory(engine, x, p, y_0, state, m, L, ws)
+        out = run_trajectory(engine, x, p, y_0, state, m, L, ws, graph=graph)
         u = noise.uniform(it, B, device)
         accept, dH = K.metropolis(out['H0'], out['H1'], u, state['active'])
         K.accept_commit(accept, state['epoch'], x, out['x_prop'], out['xt'], samples, epochs, sampling)
@@ -341,7 +341,8 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
 
     res = hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
                      epochs=int(getattr(opt, 'hmc_epochs', 60)), sampling=int(getattr(opt, 'hmc_sampling', 20)),
-                     chunk=getattr(opt, 'score_chunk', None), log=(progress if every else None) if quiet else log)
+                     chunk=getattr(opt, 'score_chunk', None), log=(progress if every else None) if quiet else log,
+                     graph=bool(getattr(opt, 'use_graph', False)))
     return res.samples[0] if n == 1 else res.samples
 
 

@@ -21,9 +21,14 @@ FFHQ_CONFIG = dict(image_size=256, num_channels=128, num_res_blocks=1, channel_m
 _DEFAULT_MULT = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
 
 
-def sinusoid(t, dim, max_period=10000):
+def sinusoid_freqs(dim, max_period=10000):
+    """Computed on the CPU exactly as the reference does (guided_diffusion/nn.py:114-116)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
+    return torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+
+
+def sinusoid(t, dim, freqs=None):
+    freqs = sinusoid_freqs(dim).to(t.device) if freqs is None else freqs
     ang = t[:, None].float() * freqs[None]
     emb = torch.cat([ang.cos(), ang.sin()], dim=-1)
     return F.pad(emb, (0, dim % 2))
@@ -103,6 +108,9 @@ class UNetModel(nn.Module):
         self.model_channels = mc = model_channels
         emb = 4 * mc
         self.time_embed = nn.Sequential(nn.Linear(mc, emb), nn.SiLU(), nn.Linear(emb, emb))
+        # resident copy of the embedding frequencies (not a checkpoint key): no host->device copy per call, which also
+        # keeps the forward capturable into a hipGraph
+        self.register_buffer('_freqs', sinusoid_freqs(mc), persistent=False)
         ch = int(channel_mult[0] * mc)
         self.input_blocks = nn.ModuleList([Stage(nn.Conv2d(in_channels, ch, 3, padding=1))])
         skip_chs, ds = [ch], 1
@@ -133,7 +141,7 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(ch, out_channels, 3, padding=1))
 
     def forward(self, x, timesteps, y=None):
-        emb = self.time_embed(sinusoid(timesteps, self.model_channels))
+        emb = self.time_embed(sinusoid(timesteps, self.model_channels, self._freqs))
         hs, h = [], x
         for blk in self.input_blocks:
             h = blk(h, emb)
