@@ -114,6 +114,7 @@ def hot_path_only(device, prob, B, steps):
     x, p, y = prob['x'].clone(), prob['p'].clone(), prob['y']
     e = K.randn_philox((B, 2 * CH, DIM, DIM), 7, 0, 0, device=device)
     gs = K.randn_philox((B, CH, DIM, DIM), 7, 0, 1, scale=1e-3, device=device)
+    ge = [torch.zeros_like(e) for _ in range(3)]            # persistent score-gradient buffers (sigma-channels stay zero)
     at =[torch.tensor([a], device=device).expand(B).contiguous() for a in (0.0033001585, 0.0777966604, 0.5214230418)]
     atn = [torch.tensor([a], device=device).expand(B).contiguous() for a in (0.0777966604, 0.5214230418, 1.0)]
     eps = torch.full((B,), EPS, dtype=torch.float64, device=device)
@@ -127,12 +128,12 @@ def hot_path_only(device, prob, B, steps):
         g2 = None
         for s in (2, 1, 0):
             if s == 2 and hasattr(op, 'fused_last_vjp'):            # data term fused into the last-step VJP
-                loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y)
+                loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y, g_e_out=ge[s])
             elif s == 2:
                 loss, g = op.data_term(cur, y, apply_clip=False)
-                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], final_clip=True)
+                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], final_clip=True, g_e_out=ge[s])
             else:
-                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], gout2=g2)
+                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], gout2=g2, g_e_out=ge[s])
             g2 = gs                                                 # stands in for the score's input-gradient
         K.leapfrog_fused(K.LF_MID, x, p, g, eps, sig, 1.0, g2=g2)
     for _ in range(3):

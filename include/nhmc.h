@@ -93,14 +93,15 @@ int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const float* at_n
  *   gin = gout (+ gout2);  if final_clip: gin *= 1[-1 <= xt_next <= 1]
  *   g_xt = ((gin*sqrt(at_next)) * 1[-1<=u<=1]) / sqrt(at)
  *   g_e[:, :C] = sqrt(1-at_next)*gin + (-g_xt)*sqrt(1-at);   g_e[:, C:] = 0
- * g_e has e_channels channels (what the score network's backward consumes).
+ * g_e has e_channels channels (what the score network's backward consumes).  fill_sigma = 1 writes the zero
+ * sigma-channels; fill_sigma = 0 leaves channels [C, e_channels) untouched (caller keeps a pre-zeroed buffer: -T).
  * g_x0 (nullable; then gout2 == NULL and final_clip == 0): split form for the plugin surface,
  * where cal_x0 and map_back are differentiated separately -- gout is then d/d add_up and g_x0
  * replaces gin*sqrt(at_next) as the gradient reaching x0_t.
  * ---------------------------------------------------------------------------------- */
 int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* g_x0, const float* xt,
                       const float* e, int e_channels, const float* at, const float* at_next, int final_clip,
-                      float* g_xt, float* g_e,
+                      float* g_xt, float* g_e, int fill_sigma,
                       int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
 
 /* a11 + a12/a13 fused: VJP of the LAST DDIM step (final clip included) with the inpainting data term computed on the
@@ -108,8 +109,8 @@ int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* g_x0, 
  * Replaces nhmc_data_inpaint + nhmc_ddim_mix_bwd(final_clip = 1) for deg = inpaint_* (same bits, -3T of traffic). */
 int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, const float* at,
                               const float* at_next, const float* y, const int32_t* slot, int64_t m,
-                              float* g_xt, float* g_e, double* loss_ws, int n_chains, int channels,
-                              int64_t hw, nhmc_stream_t stream);
+                              float* g_xt, float* g_e, int fill_sigma, double* loss_ws, int n_chains,
+                              int channels, int64_t hw, nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a12-a14  Data term: loss_b = sum (y_b - H clip(xt_b))^2 and d loss / d xt

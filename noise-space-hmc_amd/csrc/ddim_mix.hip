@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
     const float4* __restrict__ xt,
     const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
     const float* __restrict__ at_next, int final_clip, float4* __restrict__ g_xt, float4* __restrict__ g_e,
-    int64_t n4) {
+    int64_t n4, int fill_sigma) {
   const int chain = blockIdx.y;
   const Coef k = coef(at, at_next, chain);
   const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
@@ -129,8 +129,9 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
     nhmc_stnt(&g_xt[base + q], ox);
     nhmc_stnt(&g_e[ebase + q], oe);
   }
-  // learned-sigma channels of the score gradient are zero (the forward slices them away)
-  const int64_t extra = e_stride4 - n4;
+  // learned-sigma channels of the score gradient are zero (the forward slices them away); a caller that keeps a
+  // persistent, pre-zeroed g_e buffer passes fill_sigma = 0 and saves this T of writes
+  const int64_t extra = fill_sigma ? e_stride4 - n4 : 0;
   if (extra > 0) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
 __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
     const float4* __restrict__ xt, const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
     const float* __restrict__ at_next, const float* __restrict__ y, const int4* __restrict__ slot, int64_t m,
-    float4* __restrict__ g_xt, float4* __restrict__ g_e, double* __restrict__ loss_ws, int64_t n4) {
+    float4* __restrict__ g_xt, float4* __restrict__ g_e, double* __restrict__ loss_ws, int64_t n4, int fill_sigma) {
   const int chain = blockIdx.y;
   const Coef k = coef(at, at_next, chain);
   const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
     nhmc_stnt(&g_xt[base + q], ox);
     nhmc_stnt(&g_e[ebase + q], oe);
   }
-  const int64_t extra = e_stride4 - n4;
+  const int64_t extra = fill_sigma ? e_stride4 - n4 : 0;
   if (extra > 0) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -250,7 +251,7 @@ extern "C" int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const 
 
 extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const float* g_x0, const float* xt,
                                  const float* e, int e_channels, const float* at, const float* at_next, int final_clip,
-                                 float* g_xt, float* g_e, int n_chains, int channels, int64_t hw,
+                                 float* g_xt, float* g_e, int fill_sigma, int n_chains, int channels, int64_t hw,
                                  nhmc_stream_t stream) {
   if (!gout || !xt || !e || !at || !at_next || !g_xt || !g_e) return NHMC_ERR_ARG;
   if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
@@ -265,7 +266,7 @@ extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const fl
 #define NHMC_BWD(G2, SP)                                                                                  \
   NHMC_LAUNCH((k_mix_bwd<G2, SP>), grid, block, 0, st, (const float4*)gout, (const float4*)gout2,     \
                      (const float4*)g_x0, (const float4*)xt, (const float4*)e, es4, at, at_next, final_clip, \
-                     (float4*)g_xt, (float4*)g_e, n4)
+                     (float4*)g_xt, (float4*)g_e, n4, fill_sigma)
   if (g_x0) NHMC_BWD(false, true);
   else if (gout2) NHMC_BWD(true, false);
   else NHMC_BWD(false, false);
@@ -276,8 +277,8 @@ extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const fl
 // Last-step VJP fused with the inpainting data term; loss partials: nhmc_leapfrog_tiles(n_elem) per chain.
 extern "C" int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, const float* at,
                                          const float* at_next, const float* y, const int32_t* slot, int64_t m,
-                                         float* g_xt, float* g_e, double* loss_ws, int n_chains, int channels,
-                                         int64_t hw, nhmc_stream_t stream) {
+                                         float* g_xt, float* g_e, int fill_sigma, double* loss_ws, int n_chains,
+                                         int channels, int64_t hw, nhmc_stream_t stream) {
   if (!xt || !e || !at || !at_next || !y || !slot || !g_xt || !g_e || !loss_ws || m <= 0) return NHMC_ERR_ARG;
   if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
   const int64_t n_elem = (int64_t)channels * hw;
@@ -287,6 +288,6 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
   NHMC_LAUNCH(k_mix_bwd_inpaint, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
               (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)slot, m, (float4*)g_xt, (float4*)g_e, loss_ws,
-              n_elem / 4);
+              n_elem / 4, fill_sigma);
   return nhmc_launch_status();
 }

@@ -113,30 +113,35 @@ def ddim_map_back(x0_t, add_up, at_next):
     return out
 
 
-def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=None):
-    """-> (g_xt [B,C,H,W], g_e [B,e_channels,H,W]).  g_x0: split form (gout is then d/d add_up)."""
+def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=None, g_e_out=None):
+    """-> (g_xt [B,C,H,W], g_e [B,e_channels,H,W]).  g_x0: split form (gout is then d/d add_up).
+    g_e_out: a persistent buffer whose sigma-channels are already zero (they are then not rewritten)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
-    g_xt, g_e = torch.empty_like(xt), torch.empty_like(e)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.empty_like(e)
+    if g_e.shape != e.shape:
+        raise _lib.NhmcError('g_e_out must have the shape of the score output')
     rc = lib.nhmc_ddim_mix_bwd(_p(gout, torch.float32, 'gout'), _p(gout2, torch.float32, 'gout2'),
                                _p(g_x0, torch.float32, 'g_x0'), _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
-                               int(final_clip), _p(g_xt), _p(g_e), B, Cc, hw, _stream())
+                               int(final_clip), _p(g_xt), _p(g_e), int(g_e_out is None), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd')
     return g_xt, g_e
 
 
-def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot):
+def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot, g_e_out=None):
     """Last-step VJP fused with the inpainting data term -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
-    g_xt, g_e = torch.empty_like(xt), torch.empty_like(e)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.empty_like(e)
     tiles = leapfrog_tiles(Cc * hw)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
     rc = lib.nhmc_ddim_mix_bwd_inpaint(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                        _p(y, torch.float32, 'y'), _p(slot, torch.int32, 'slot'), y.shape[1], _p(g_xt),
-                                       _p(g_e), _p(ws), B, Cc, hw, _stream())
+                                       _p(g_e), int(g_e_out is None), _p(ws), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd_inpaint')
     return sum_partials(ws, tiles, B), g_xt, g_e
 

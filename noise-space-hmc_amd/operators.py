@@ -78,9 +78,9 @@ class Inpainting(H_functions):
     def data_term(self, xt, y, apply_clip=True):
         return K.data_inpaint(xt, y, self.slot, apply_clip)
 
-    def fused_last_vjp(self, xt_in, e, at, at_next, y):
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
         """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
-        return K.ddim_mix_bwd_inpaint(xt_in, e, at, at_next, y, self.slot)
+        return K.ddim_mix_bwd_inpaint(xt_in, e, at, at_next, y, self.slot, g_e_out=g_e_out)
 
 
 class SuperResolution(H_functions):

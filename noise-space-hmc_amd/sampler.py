@@ -102,6 +102,7 @@ class LeapfrogEngine:
         self.image_map = image_map
         self.fuse_last = True                  # use operator.fused_last_vjp when it exists (inpainting)
         self._graphs = {}                      # (n, shape of y) -> captured decode+gradient of one chunk
+        self._ge = {}                          # score-output shape -> persistent g_e buffers (sigma-channels stay zero)
         steps = list(zip(reversed(seq), reversed(seq_next)))
         from .schedule import alpha_bar_table
         table = alpha_table.to(device).float() if alpha_table is not None else alpha_bar_table(b)
@@ -187,15 +188,21 @@ class LeapfrogEngine:
         if not fused:
             loss_out.copy_(l)
         g2 = None
+        # one persistent score-gradient buffer per DDIM step and shape: its sigma-channels are zeroed once and never
+        # rewritten (the mix VJP writes only the first C channels: -T of traffic per step)
+        key = tuple(ins[0][1].shape)
+        bufs = self._ge.get(key)
+        if bufs is None:
+            bufs = self._ge[key] = [torch.zeros_like(ins[0][1]) for _ in range(S)]
         for s in reversed(range(S)):
             leaf, e_c = ins[s]
             if fused and s == S - 1:                  # data term + last-step VJP in one kernel
                 l, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, self.at[s].expand(n),
-                                                                self.at_next[s].expand(n), y)
+                                                                self.at_next[s].expand(n), y, g_e_out=bufs[s])
                 loss_out.copy_(l)
             else:
                 g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
-                                               final_clip=(s == S - 1), gout2=g2)
+                                               final_clip=(s == S - 1), gout2=g2, g_e_out=bufs[s])
             (g_score,) = torch.autograd.grad(outs[s], leaf, g_e)
             outs[s] = None
             g, g2 = g_direct, g_score.contiguous()

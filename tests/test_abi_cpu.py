@@ -60,7 +60,7 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.nhmc_leapfrog_fused(1, a16, a16, a16, null, a16, a16, 1.0, 70000, 1024, null, null) == 3   # SHAPE
     assert lib.nhmc_ddim_mix_fwd(a16, a16, 5, a16, a16, 0, a16, null, null, 1, 3, 256, null) == 3         # e_channels
     assert lib.nhmc_ddim_mix_fwd(a16, a16, 6, a16, a16, 0, null, null, null, 1, 3, 256, null) == 1        # no output
-    assert lib.nhmc_ddim_mix_bwd(a16, a16, a16, a16, a16, 6, a16, a16, 0, a16, a16, 1, 3, 256, null) == 1  # split + gout2
+    assert lib.nhmc_ddim_mix_bwd(a16, a16, a16, a16, a16, 6, a16, a16, 0, a16, a16, 1, 1, 3, 256, null) == 1  # split + gout2
     assert lib.nhmc_data_sr(a16, a16, 3, 1, a16, a16, 1, 3, 256, null) == 3                                # ratio 3
     assert lib.nhmc_data_sr(a16, a16, 4, 1, a16, a16, 1, 3, 250, null) == 3                                # dim % 4
     assert lib.nhmc_spectral_apply(a16, a16, a16, a16, a16, a16, a16, a16, 1, 3, 48, null) == 3           # dim % 32
