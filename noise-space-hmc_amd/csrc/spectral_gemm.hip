@@ -30,7 +30,7 @@ enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3 };
 constexpr int BK = 32;
 
 template <int T, int NW, int EPI, bool PRECLIP>
-__global__ __launch_bounds__(64 * NW * NW, NW == 2 ? 4 : 1) void k_sgemm(
+__global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1) void k_sgemm(
     const float* __restrict__ IN, const float* __restrict__ S, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int K, int R, int C,
     int channels) {
