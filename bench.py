@@ -208,9 +208,11 @@ def main():
     eps = torch.full((B,), EPS, dtype=torch.float64, device=device)
     sig = torch.full((B,), 2 * SIGMA0_CLI + 1.6, dtype=torch.float64, device=device)     # sigma_y at epoch 0
     in_situ = []
+    last = {}
 
     def step(timed):
         xt, loss, ga, gb = eng.decode_and_grad(x, y)
+        last['loss'] = loss
         if timed:
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -234,6 +236,19 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         value = world * B * args.steps / dt
 
+    # the one collective of the design: per-chain results gathered once, after the timed region (RCCL over xGMI at N > 1)
+    gather = None
+    if not args.kernel_only:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = torch.stack([last['loss'].float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
+        if args.rehearse_shared_gpu:
+            allstats = sharding.gather_chains(stats.cpu(), world * B, rank, world)
+        else:
+            allstats = sharding.gather_chains(stats, world * B, rank, world)
+        torch.cuda.synchronize()
+        gather = dict(chains=int(allstats.shape[0]), ms=round(1e3 * (time.perf_counter() - t0), 3),
+                      loss_mean=float(allstats[:, 0].double().mean()))
     roof = hot = cpu = single = None
     if rank == 0 and not args.kernel_only:
         # the reference's own operating point: ONE chain (its hmc() is batch-1 only); BASELINE.md derives
@@ -293,7 +308,7 @@ def main():
                                    'timesteps=3, 64 chains per GPU, FFHQ U-Net architecture random-init fp32',
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
-            'roofline': roofline, 'hot_path_only': hot, 'single_chain': single, 'cpu_baseline': cpu,
+            'roofline': roofline, 'hot_path_only': hot, 'single_chain': single, 'final_gather': gather, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     sharding.barrier()
