@@ -75,6 +75,59 @@ __global__ __launch_bounds__(64 * NW * NW) void k_gemm(const float* __restrict__
       }
 }
 
+// Variant 2: WM x WN waves (rectangular wave grid), optional rotated k order per block (stagger), optional bound
+template <int T, int WM, int WN, int BK, bool ROT, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void k_gemm2(const float* __restrict__ IN, const float* __restrict__ S,
+                                                                float* __restrict__ OUT, int d) {
+  constexpr int NT = 64 * WM * WN, FRI = T / (32 * WM), FRJ = T / (32 * WN), NV = (BK * T / 4) / NT;
+  __shared__ float As[BK * T];
+  __shared__ float Bs[BK * T];
+  const int img = blockIdx.z, tr = blockIdx.y * T, tc = blockIdx.x * T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wi = wave / WN, wj = wave % WN, lr = lane & 31, lh = lane >> 5;
+  const float* __restrict__ X = IN + (long)img * d * d;
+  f32x16 acc[FRI][FRJ];
+#pragma unroll
+  for (int a = 0; a < FRI; ++a)
+#pragma unroll
+    for (int b = 0; b < FRJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int nk = d / BK;
+  const int rot = ROT ? (int)((blockIdx.x + blockIdx.y * 3 + blockIdx.z * 5) % nk) : 0;
+  for (int it = 0; it < nk; ++it) {
+    const int k0 = ((it + rot) % nk) * BK;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + v * NT, kk = idx / (T / 4), c4 = idx % (T / 4);
+      *reinterpret_cast<v4f*>(&As[kk * T + c4 * 4]) = *reinterpret_cast<const v4f*>(&X[(long)(k0 + kk) * d + tr + c4 * 4]);
+      *reinterpret_cast<v4f*>(&Bs[kk * T + c4 * 4]) = *reinterpret_cast<const v4f*>(&S[(long)(k0 + kk) * d + tc + c4 * 4]);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[FRI], b[FRJ];
+#pragma unroll
+      for (int f = 0; f < FRI; ++f) a[f] = As[(kk + lh) * T + (wi * FRI + f) * 32 + lr];
+#pragma unroll
+      for (int f = 0; f < FRJ; ++f) b[f] = Bs[(kk + lh) * T + (wj * FRJ + f) * 32 + lr];
+#pragma unroll
+      for (int fa = 0; fa < FRI; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < FRJ; ++fb) acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fa], b[fb], acc[fa][fb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int fa = 0; fa < FRI; ++fa)
+#pragma unroll
+    for (int fb = 0; fb < FRJ; ++fb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tr + (wi * FRI + fa) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = tc + (wj * FRJ + fb) * 32 + lr;
+        OUT[(long)img * d * d + (long)row * d + col] = acc[fa][fb][r];
+      }
+}
+
 int main() {
   const int d = 256, NIMG = 192;
   const size_t n = (size_t)NIMG * d * d;
@@ -106,11 +159,13 @@ int main() {
   };
 #define G(T, NW, BK, PIPE, LPF) bench("T" #T " NW" #NW " BK" #BK " PIPE" #PIPE " LPF" #LPF, [&]() { \
     hipLaunchKernelGGL((k_gemm<T, NW, BK, PIPE, LPF>), dim3(d / T, d / T, NIMG), dim3(64 * NW * NW), 0, 0, IN, S, OUT, d); })
+#define H(T, WM, WN, BK, ROT, MINW) bench("v2 T" #T " W" #WM "x" #WN " BK" #BK " ROT" #ROT " MINW" #MINW, [&]() { \
+    hipLaunchKernelGGL((k_gemm2<T, WM, WN, BK, ROT, MINW>), dim3(d / T, d / T, NIMG), dim3(64 * WM * WN), 0, 0, IN, S, OUT, d); })
   for (int rep = 0; rep < 2; ++rep) {
-    G(128, 2, 32, 0, false); G(128, 2, 32, 1, false); G(128, 2, 32, 2, false); G(128, 2, 32, 0, true); G(128, 2, 32, 1, true); G(128, 2, 32, 2, true);
-    G(128, 2, 16, 0, false); G(128, 2, 16, 1, false); G(128, 2, 16, 2, false); G(128, 2, 16, 2, true); G(128, 2, 16, 1, true);
-    G(64, 2, 32, 0, false); G(64, 2, 32, 1, false); G(64, 2, 32, 2, true);
-    G(128, 2, 64, 0, false); G(128, 2, 64, 1, false);
+    G(128, 2, 32, 0, false);
+    H(128, 2, 2, 32, false, 1); H(128, 2, 2, 32, true, 1); H(128, 2, 2, 32, false, 4); H(128, 2, 2, 32, true, 4);
+    H(128, 4, 2, 32, false, 1); H(128, 4, 2, 32, true, 1); H(128, 2, 4, 32, true, 1); H(128, 4, 4, 32, true, 1);
+    H(128, 2, 2, 16, true, 1); H(128, 4, 2, 16, true, 1); H(128, 2, 2, 64, true, 1);
   }
   return 0;
 }
