@@ -185,6 +185,44 @@ def cpu_baseline(seed=5678):
                 sample=f'oracle (oracle/hmc_ref.py) leapfrog step, B=1, 1 step, FFHQ U-Net fp32 on CPU: {dt:.1f} s')
 
 
+def single_chain_rate(eng, x, p, y, eps, sig, with_graph):
+    """The reference's own operating point: ONE chain (its hmc() is batch-1 only); BASELINE.md derives ~3.2 leapfrog
+    steps/s for it from the authors' logs (unstated NVIDIA GPU).  Runs last: a failed graph capture must not disturb
+    the measurements above."""
+    import nhmc.kernels as K
+    x1, p1, y1 = x[:1].clone(), p[:1].clone(), y[:1].contiguous()
+    e1, s1 = eps[:1].contiguous(), sig[:1].contiguous()
+    for _ in range(2):
+        _, _, ga, gb = eng.decode_and_grad(x1, y1)
+        K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        _, _, ga, gb = eng.decode_and_grad(x1, y1)
+        K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+    torch.cuda.synchronize()
+    eager = 5 / (time.perf_counter() - t0)
+    graphed = None
+    try:                                                 # same step replayed as one hipGraph per decode+gradient
+        if not with_graph:
+            raise RuntimeError('not measured at N > 1')
+        for _ in range(2):
+            _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
+            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
+            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+        torch.cuda.synchronize()
+        graphed = round(5 / (time.perf_counter() - t0), 2)
+    except RuntimeError as exc:                          # capture support is the framework's, not ours: report, go on
+        graphed = f'capture failed: {str(exc)[:80]}'
+    single = dict(value=round(eager, 2), value_hipgraph=graphed, unit='leapfrog steps/s', chains=1,
+                  reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
+    return single
+
+
 def main():
     args = parse()
     import nhmc.kernels as K
@@ -250,37 +288,6 @@ def main():
         gather = dict(chains=int(allstats.shape[0]), ms=round(1e3 * (time.perf_counter() - t0), 3),
                       loss_mean=float(allstats[:, 0].double().mean()))
     roof = hot = cpu = single = None
-    if rank == 0 and not args.kernel_only:
-        # the reference's own operating point: ONE chain (its hmc() is batch-1 only); BASELINE.md derives
-        # ~3.2 leapfrog steps/s for it from the authors' logs (unstated NVIDIA GPU)
-        x1, p1, y1 = x[:1].clone(), p[:1].clone(), y[:1].contiguous()
-        e1, s1 = eps[:1].contiguous(), sig[:1].contiguous()
-        for _ in range(2):
-            _, _, ga, gb = eng.decode_and_grad(x1, y1)
-            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            _, _, ga, gb = eng.decode_and_grad(x1, y1)
-            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
-        torch.cuda.synchronize()
-        eager = 5 / (time.perf_counter() - t0)
-        graphed = None
-        try:                                                 # same step replayed as one hipGraph per decode+gradient
-            for _ in range(2):
-                _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
-                K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
-                K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
-            torch.cuda.synchronize()
-            graphed = round(5 / (time.perf_counter() - t0), 2)
-        except RuntimeError as exc:                          # capture support is the framework's, not ours: report, go on
-            graphed = f'capture failed: {str(exc)[:80]}'
-        single = dict(value=round(eager, 2), value_hipgraph=graphed, unit='leapfrog steps/s', chains=1,
-                      reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
     if rank == 0:
         roof = leapfrog_roofline(device, B, args.roofline_launches)
         hot = hot_path_only(device, prob, B, 20)
@@ -297,6 +304,8 @@ def main():
                         **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in roof.items() if k != 'achieved'})
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+        if not args.kernel_only:
+            single = single_chain_rate(eng, x, p, y, eps, sig, with_graph=(world == 1))
         line = {
             'metric': f'HMC leapfrog chain-steps/sec (256x256x3 FFHQ {args.deg}, U-Net score in the loop)',
             'value': None if value is None else round(value, 3), 'unit': 'chain-steps/s', 'n_gpus': world,
