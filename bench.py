@@ -277,9 +277,10 @@ def main():
     # the one collective of the design: per-chain results gathered once, after the timed region (RCCL over xGMI at N > 1)
     gather = None
     if not args.kernel_only:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         stats = torch.stack([last['loss'].float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
+        torch.cuda.synchronize()
+        sharding.barrier()
+        t0 = time.perf_counter()                                   # times the collective alone
         if args.rehearse_shared_gpu:
             allstats = sharding.gather_chains(stats.cpu(), world * B, rank, world)
         else:
