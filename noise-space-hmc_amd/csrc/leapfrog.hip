@@ -11,7 +11,7 @@
 
 namespace {
 
-template <int MODE, bool HAS_G2>
+template <int MODE, bool HAS_G2, int VPT>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
     float4* __restrict__ x, float4* __restrict__ p, const float4* __restrict__ g,
     const float4* __restrict__ g2, const double* __restrict__ eps, const double* __restrict__ sigma_y,
@@ -24,12 +24,12 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
   const float ex = (float)(e * m_inv);                // epsilon * m**(-1)
 
   const int64_t base = (int64_t)chain * n4;
-  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * VPT) + threadIdx.x;
 
-  float4 xv[NHMC_VEC_PER_THREAD], pv[NHMC_VEC_PER_THREAD], gv[NHMC_VEC_PER_THREAD];
-  bool ok[NHMC_VEC_PER_THREAD];
+  float4 xv[VPT], pv[VPT], gv[VPT];
+  bool ok[VPT];
 #pragma unroll
-  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+  for (int i = 0; i < VPT; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     ok[i] = q < n4;
     if (ok[i]) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
 
   float sx = 0.0f, sp = 0.0f;
 #pragma unroll
-  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+  for (int i = 0; i < VPT; ++i) {
     if (!ok[i]) continue;
     float* xe = reinterpret_cast<float*>(&xv[i]);
     float* pe = reinterpret_cast<float*>(&pv[i]);
@@ -88,12 +88,16 @@ template <int MODE>
 int launch(float* x, float* p, const float* g, const float* g2, const double* eps, const double* sigma_y,
            double m_inv, int n_chains, int64_t n_elem, double* ws, hipStream_t st) {
   const int64_t n4 = n_elem / 4;
-  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  // FIRST / LAST write one partial per nhmc_leapfrog_tiles() tile (2 float4 per thread); MID has no reduction and
+  // runs 1 float4 per thread (measured: 41.2 us vs 41.8 us at B = 64, tools/lf_bench.hip)
+  constexpr int VPT = MODE == NHMC_LF_MID ? 1 : NHMC_VEC_PER_THREAD;
+  const unsigned tiles = MODE == NHMC_LF_MID ? (unsigned)((n4 + NHMC_BLOCK - 1) / NHMC_BLOCK) : (unsigned)nhmc_leapfrog_tiles(n_elem);
+  dim3 grid(tiles, (unsigned)n_chains), block(NHMC_BLOCK);
   if (g2)
-    NHMC_LAUNCH((k_leapfrog<MODE, true>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
+    NHMC_LAUNCH((k_leapfrog<MODE, true, VPT>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
                        (const float4*)g2, eps, sigma_y, m_inv, n4, ws);
   else
-    NHMC_LAUNCH((k_leapfrog<MODE, false>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
+    NHMC_LAUNCH((k_leapfrog<MODE, false, VPT>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
                        (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws);
   return nhmc_launch_status();
 }

@@ -70,7 +70,7 @@ if acc:
             fe = sum(d['FETCH_SIZE']) / max(1, len(d['FETCH_SIZE']))
             wr = sum(d['WRITE_SIZE']) / max(1, len(d['WRITE_SIZE']))
             w.writerow([k[:110], len(d['FETCH_SIZE']), f'{fe:.1f}', f'{wr:.1f}', f'{(2 * fe + wr) * 1024:.0f}'])
-            if k.startswith('k_leapfrog<1, false>'):
+            if k.startswith('k_leapfrog<1, false'):
                 json.dump({'kernel': k, 'fetch_size_kib': fe, 'write_size_kib': wr,
                            'hbm_bytes_per_launch': (2 * fe + wr) * 1024,
                            'note': 'FETCH_SIZE doubled (gfx950 wide-read correction), separate --pmc passes, source ' + tag},
