@@ -3,8 +3,8 @@
 // :715 (last half-step undo) and produces the per-chain sums the Hamiltonians at :697/:717 need.
 //
 // HBM-bound streaming kernel: MID reads x,p,g and writes x,p = 20 B/element (5T per chain).
-// grid = (tiles, chains); 256 threads; every thread owns 2 float4 per stream (non-temporal), strided by the
-// block so each wave-instruction touches 1 KiB contiguous.  Per-chain scalars are fp64 device
+// grid = (tiles, chains); 256 threads; every thread owns VPT float4 per stream (non-temporal; 2 in FIRST / LAST,
+// 1 in MID), strided by the block so each wave-instruction touches 1 KiB contiguous.  Per-chain scalars are fp64 device
 // values rounded once to fp32, exactly as `python_float * tensor` does in the reference.
 // Compiled with -ffp-contract=off: mul/add stay separate, matching the reference's ATen op order.
 #include "nhmc_common.h"
