@@ -112,6 +112,14 @@ int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, c
                               float* g_xt, float* g_e, int fill_sigma, double* loss_ws, int n_chains,
                               int channels, int64_t hw, nhmc_stream_t stream);
 
+/* a11 + a12/a14 fused: the same for the super-resolution operator (obs_functions/Hfuncs.py:180-234), ratio in
+ * {2,4,8,16}: r = y - blockmean(clip(xt_next)), loss partials (nhmc_sr_tiles(channels, dim, ratio) per chain),
+ * gin = -2 r / ratio^2.  Replaces nhmc_data_sr + nhmc_ddim_mix_bwd(final_clip = 1) (same bits, -3T of traffic).
+ * Writes channels [0, channels) of g_e only: the caller keeps the sigma-channels of g_e zero. */
+int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_channels, const float* at, const float* at_next,
+                         const float* y, int ratio, float* g_xt, float* g_e, double* loss_ws, int n_chains,
+                         int channels, int dim, nhmc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a12-a14  Data term: loss_b = sum (y_b - H clip(xt_b))^2 and d loss / d xt
  *                                          main_sampling.py:693-695,709-711

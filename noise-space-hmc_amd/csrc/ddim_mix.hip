@@ -201,6 +201,92 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
   if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
 }
 
+// Last DDIM step VJP fused with the super-resolution (r x r block mean) data term.  Work item = one float4 strip of
+// one output row (as k_sr in data_term.hip): a thread walks the R rows of its strip twice -- pass 1 recomputes the
+// clipped decode from (xt, e), sums it and keeps two mask bits per element; pass 2 turns the block residual into
+// g_xt / g_e.  Same summation order as k_mix_fwd + k_sr + k_mix_bwd, hence the same bits, with -3T of traffic.
+template <int R>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_sr(
+    const float4* __restrict__ xt, const float4* __restrict__ e, int e_channels, const float* __restrict__ at,
+    const float* __restrict__ at_next, const float* __restrict__ y, float4* __restrict__ g_xt,
+    float4* __restrict__ g_e, double* __restrict__ loss_ws, int dim, int channels) {
+  const int chain = blockIdx.y;
+  const Coef k = coef(at, at_next, chain);
+  const int w4 = dim / 4, yd = dim / R;
+  const int64_t items = (int64_t)channels * yd * w4;
+  const int64_t item = (int64_t)blockIdx.x * NHMC_BLOCK + threadIdx.x;
+  const bool live = item < items;
+  const int64_t it = live ? item : 0;
+  const int s = (int)(it % w4);
+  const int i = (int)((it / w4) % yd);
+  const int plane = (int)(it / ((int64_t)w4 * yd));
+  const int64_t xrow0 = ((int64_t)chain * channels + plane) * (int64_t)dim * w4 + (int64_t)i * R * w4 + s;
+  const int64_t erow0 = ((int64_t)chain * e_channels + plane) * (int64_t)dim * w4 + (int64_t)i * R * w4 + s;
+  const float* yplane = y + ((int64_t)chain * channels + plane) * (int64_t)yd * yd;
+  constexpr int LANES = R >= 4 ? R / 4 : 1;     // strips that share one block
+  constexpr int BPS = R >= 4 ? 1 : 4 / R;       // blocks per strip (R = 2 -> 2)
+  const float inv = 1.0f / (float)(R * R);
+
+  float bs[BPS];
+#pragma unroll
+  for (int b = 0; b < BPS; ++b) bs[b] = 0.0f;
+  unsigned in_pre = 0u, in_u = 0u;              // bit rr*4+c: 1[-1 <= pre <= 1], 1[-1 <= u <= 1]   (R <= 8 rows per word)
+  unsigned in_pre_hi = 0u, in_u_hi = 0u;        // rows 8..15 (R = 16)
+  if (live) {
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const float4 xv = nhmc_ldnt(&xt[xrow0 + (int64_t)rr * w4]), ev = nhmc_ldnt(&e[erow0 + (int64_t)rr * w4]);
+      const float* xe = reinterpret_cast<const float*>(&xv);
+      const float* ee = reinterpret_cast<const float*>(&ev);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float u = (xe[c] - ee[c] * k.c1) / k.c2;
+        const float pre = k.c3 * nhmc_clip1(u) + k.c4 * ee[c];
+        bs[BPS == 1 ? 0 : c / R] += nhmc_clip1(pre);
+        const unsigned bit = 1u << (((rr & 7) << 2) + c);
+        if (rr < 8) { if (pre >= -1.0f && pre <= 1.0f) in_pre |= bit; if (u >= -1.0f && u <= 1.0f) in_u |= bit; }
+        else        { if (pre >= -1.0f && pre <= 1.0f) in_pre_hi |= bit; if (u >= -1.0f && u <= 1.0f) in_u_hi |= bit; }
+      }
+    }
+  }
+  if (LANES > 1) {
+#pragma unroll
+    for (int off = 1; off < LANES; off <<= 1) bs[0] += __shfl_xor(bs[0], off, NHMC_WAVE);
+  }
+  float acc = 0.0f, resid[BPS];
+#pragma unroll
+  for (int b = 0; b < BPS; ++b) {
+    const int j = BPS == 1 ? (s * 4) / R : s * BPS + b;
+    resid[b] = live ? yplane[(int64_t)i * yd + j] - bs[b] * inv : 0.0f;
+    if (live && (LANES == 1 || (s % LANES) == 0)) acc += resid[b] * resid[b];
+  }
+  if (live) {
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      float4 ox, oe;
+      float* gx = reinterpret_cast<float*>(&ox);
+      float* gee = reinterpret_cast<float*>(&oe);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned bit = 1u << (((rr & 7) << 2) + c);
+        const float mp = ((rr < 8 ? in_pre : in_pre_hi) & bit) ? 1.0f : 0.0f;
+        const float mu = ((rr < 8 ? in_u : in_u_hi) & bit) ? 1.0f : 0.0f;
+        float gin = (-(2.0f * resid[BPS == 1 ? 0 : c / R])) * inv;   // data-term gradient (k_sr, no clip mask there)
+        gin = gin * mp;                                               // final clip mask
+        const float gu = ((gin * k.c3) * mu) / k.c2;
+        gx[c] = gu;
+        gee[c] = k.c4 * gin + (-gu) * k.c1;
+      }
+      nhmc_stnt(&g_xt[xrow0 + (int64_t)rr * w4], ox);
+      nhmc_stnt(&g_e[erow0 + (int64_t)rr * w4], oe);
+    }
+  }
+  __shared__ double red[4];
+  double v[1] = {(double)acc};
+  nhmc_block_sum<1>(v, red);
+  if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
+}
+
 bool bad_shape(int n_chains, int channels, int64_t hw, int e_channels) {
   return n_chains <= 0 || n_chains > 65535 || channels <= 0 || hw <= 0 ||
          (e_channels != channels && e_channels != 2 * channels);
@@ -289,5 +375,26 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_
   NHMC_LAUNCH(k_mix_bwd_inpaint, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
               (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)slot, m, (float4*)g_xt, (float4*)g_e, loss_ws,
               n_elem / 4, fill_sigma);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_channels, const float* at,
+                                    const float* at_next, const float* y, int ratio, float* g_xt, float* g_e,
+                                    double* loss_ws, int n_chains, int channels, int dim, nhmc_stream_t stream) {
+  if (!xt || !e || !at || !at_next || !y || !g_xt || !g_e || !loss_ws) return NHMC_ERR_ARG;
+  if (dim <= 0 || (dim % 4) || bad_shape(n_chains, channels, (int64_t)dim * dim, e_channels)) return NHMC_ERR_SHAPE;
+  if (!(ratio == 2 || ratio == 4 || ratio == 8 || ratio == 16) || (dim % ratio)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e)) return NHMC_ERR_ALIGN;
+  dim3 grid((unsigned)nhmc_sr_tiles(channels, dim, ratio), (unsigned)n_chains), block(NHMC_BLOCK);
+#define NHMC_BSR(R)                                                                                              \
+  NHMC_LAUNCH(k_mix_bwd_sr<R>, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e, e_channels, \
+              at, at_next, y, (float4*)g_xt, (float4*)g_e, loss_ws, dim, channels)
+  switch (ratio) {
+    case 2: NHMC_BSR(2); break;
+    case 4: NHMC_BSR(4); break;
+    case 8: NHMC_BSR(8); break;
+    default: NHMC_BSR(16); break;
+  }
+#undef NHMC_BSR
   return nhmc_launch_status();
 }

@@ -146,6 +146,24 @@ def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot, g_e_out=None):
     return sum_partials(ws, tiles, B), g_xt, g_e
 
 
+def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None):
+    """Last-step VJP fused with the super-resolution data term -> (loss [B] float64, g_xt, g_e)."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    dim = xt.shape[2]
+    if xt.shape[3] != dim:
+        raise _lib.NhmcError('square images only')
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)          # the kernel writes channels [0, C) only
+    tiles = lib.nhmc_sr_tiles(Cc, dim, ratio)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    rc = lib.nhmc_ddim_mix_bwd_sr(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                  _p(y, torch.float32, 'y'), ratio, _p(g_xt), _p(g_e), _p(ws), B, Cc, dim, _stream())
+    _lib.check(rc, 'nhmc_ddim_mix_bwd_sr')
+    return sum_partials(ws, tiles, B), g_xt, g_e
+
+
 # ---- a12-a15 --------------------------------------------------------------------------------
 def sum_partials(ws, tiles, n_chains, stride=1, offset=0):
     lib = _lib.load()

@@ -92,6 +92,8 @@ class SuperResolution(H_functions):
         self.y_dim = img_dim // ratio
         self.M = channels * self.y_dim ** 2
         self.device = device
+        if ratio in (2, 4, 8, 16):                     # the fused kernel keeps two mask bits per element in registers
+            self.fused_last_vjp = self._fused_last_vjp
 
     def singulars(self):
         return torch.full((self.M,), 1.0 / self.ratio, device=self.device)
@@ -108,6 +110,10 @@ class SuperResolution(H_functions):
 
     def data_term(self, xt, y, apply_clip=True):
         return K.data_sr(xt, y, self.ratio, apply_clip)
+
+    def _fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
+        """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
+        return K.ddim_mix_bwd_sr(xt_in, e, at, at_next, y, self.ratio, g_e_out=g_e_out)
 
 
 def _band_matrix(kernel, img_dim):

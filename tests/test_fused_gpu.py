@@ -44,3 +44,49 @@ def test_engine_with_and_without_fusion_agree(tiny_score):
     b = eng.decode_and_grad(x, y)
     for u, v in zip(a, b):
         assert torch.equal(u, v) or float((u - v).abs().max()) <= 1e-12 * float(v.abs().max())
+
+
+@pytest.mark.parametrize('dim,B,ratio', [(16, 1, 2), (32, 3, 4), (64, 2, 8), (48, 2, 16), (256, 2, 4), (256, 2, 16)])
+def test_fused_sr_last_vjp_equals_two_kernel_path(dim, B, ratio):
+    import nhmc.kernels as K
+    from nhmc import operators
+    g_ = torch.Generator().manual_seed(dim + ratio)
+    op = operators.SuperResolution(3, dim, ratio, 'cuda')
+    xt = (torch.randn(B, 3, dim, dim, generator=g_) * 0.5).cuda()
+    e = torch.randn(B, 6, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    b = osched.betas_fp32()
+    at = osched.alpha_bar(b, torch.full((B,), 250)).cuda()
+    atn = osched.alpha_bar(b, torch.full((B,), -1)).cuda()
+    cur = K.ddim_mix_fwd(xt, e, at, atn, final_clip=True)['xt_next']
+    loss_a, g = op.data_term(cur, y, apply_clip=False)
+    gx_a, ge_a = K.ddim_mix_bwd(g, xt, e, at, atn, final_clip=True)
+    loss_b, gx_b, ge_b = op.fused_last_vjp(xt, e, at, atn, y)
+    assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b)
+    assert float((loss_a - loss_b).abs().max() / loss_a.abs().max()) < 1e-12
+    # persistent-buffer form: only channels [0, C) are written
+    buf = torch.full_like(e, 7.0)
+    _, _, ge_c = op.fused_last_vjp(xt, e, at, atn, y, g_e_out=buf)
+    assert ge_c is buf and torch.equal(buf[:, :3], ge_a[:, :3]) and bool((buf[:, 3:] == 7.0).all())
+
+
+def test_sr_ratio_32_keeps_the_two_kernel_path():
+    from nhmc import operators
+    assert not hasattr(operators.SuperResolution(3, 64, 32, 'cuda'), 'fused_last_vjp')
+    assert hasattr(operators.SuperResolution(3, 64, 4, 'cuda'), 'fused_last_vjp')
+
+
+def test_engine_sr_with_and_without_fusion_agree(tiny_score):
+    from nhmc import operators, plugin, sampler
+    dim, B = 32, 3
+    g_ = torch.Generator().manual_seed(11)
+    op = operators.SuperResolution(3, dim, 4, 'cuda')
+    algo = plugin.HMC(copy.deepcopy(tiny_score).cuda(), op, 0.1)
+    eng = sampler.LeapfrogEngine(algo.score, op, osched.betas_fp32().cuda(), SEQ, SEQ_NEXT, torch.device('cuda'))
+    x = torch.randn(B, 3, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    a = eng.decode_and_grad(x, y)
+    eng.fuse_last = False
+    b = eng.decode_and_grad(x, y)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v) or float((u - v).abs().max()) <= 1e-12 * float(v.abs().max())

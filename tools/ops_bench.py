@@ -38,3 +38,11 @@ for deg, nbytes in (('cs4', None), ('sr_bicubic4', None), ('color', None), ('deb
     yy = torch.randn(B, o.M, device=dev)
     ms = timeit(lambda: o.data_term(x, yy, True), 10)
     print(f'{deg} data term B={B}: {ms*1e3:.1f} us  ({T/ms/1e6:.0f} GB/s per T moved)')
+# fused (data term + last DDIM-step VJP) kernels: R xt, R e[:C], W g_xt, W g_e[:C] = 4T
+e6 = K.randn_philox((B, 6, 256, 256), 1, 0, 2)
+ge = torch.zeros_like(e6)
+at = torch.full((B,), 0.5214230418, device=dev)
+an = torch.ones(B, device=dev)
+for name, o, yy in (('inpaint', opi, yi), ('sr4', op4, y4), ('sr16', op16, y16)):
+    ms = timeit(lambda: o.fused_last_vjp(x, e6, at, an, yy, g_e_out=ge))
+    print(f'{name} fused last VJP B={B}: {ms*1e3:.1f} us  {(4*T)/ms/1e6:.0f} GB/s (4T)')
