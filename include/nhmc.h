@@ -197,6 +197,13 @@ int nhmc_spectral_tiles(int channels, int dim);
 int nhmc_data_spectral(const float* xt, const float* y, const float* factors, const float* Dmap,
                        int apply_clip, float* g_xt, double* loss_ws, float* tmp,
                        int n_chains, int channels, int dim, nhmc_stream_t stream);
+/* a11 + a12/a15 fused: data term on xt_next (the clipped decode of the LAST DDIM step, as nhmc_ddim_mix_fwd wrote it)
+ * with the step's VJP applied in the last product's epilogue: writes g_xt and channels [0, channels) of g_e (the caller
+ * keeps its sigma-channels zero).  Replaces nhmc_data_spectral(apply_clip = 0) + nhmc_ddim_mix_bwd(final_clip = 1). */
+int nhmc_data_spectral_vjp(const float* xt_next, const float* y, const float* factors, const float* Dmap,
+                           const float* xt, const float* e, int e_channels, const float* at, const float* at_next,
+                           float* g_xt, float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
+                           nhmc_stream_t stream);
 
 /* Separable strided convolution (SRConv / sr_bicubic, Hfuncs.py:527-607): H(X) = A X A^T, A [sd][d] the
  * (singular-value-truncated) 1-D kernel matrix; H^T(Y) = A^T Y A; H^+(Y) = A+ Y A+^T.  Same MFMA kernel, rectangular.

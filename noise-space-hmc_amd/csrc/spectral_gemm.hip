@@ -26,14 +26,16 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3 };
+enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4 };
+// EPI_VJP: the gradient tile goes straight through the VJP of the last DDIM step (k_mix_bwd, final clip included)
+struct VjpArgs { const float* e; float* g_e; const float* at; const float* at_next; int e_channels; };
 constexpr int BK = 32;
 
 template <int T, int NW, int EPI, bool PRECLIP>
 __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1) void k_sgemm(
     const float* __restrict__ IN, const float* __restrict__ S, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int K, int R, int C,
-    int channels) {
+    int channels, VjpArgs vj) {
   constexpr int NT = 64 * NW * NW;
   constexpr int FR = T / (32 * NW);
   constexpr int NV = (BK * T / 4) / NT;          // float4 per thread per operand tile
@@ -95,6 +97,18 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
   const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * R * C : nullptr;
   const float* __restrict__ aux_img = aux ? aux + (int64_t)img * R * C : nullptr;
   float lsum = 0.0f;
+  // EPI_VJP: aux = the DDIM step's input xt; e / g_e are [chain][e_channels][R][C]
+  const float* __restrict__ e_img = nullptr;
+  float* __restrict__ ge_img = nullptr;
+  float c1 = 0.f, c2 = 1.f, c3 = 0.f, c4 = 0.f;
+  if (EPI == EPI_VJP) {
+    const int chain = img / channels;
+    const int64_t eoff = ((int64_t)chain * vj.e_channels + c) * R * C;
+    e_img = vj.e + eoff;
+    ge_img = vj.g_e + eoff;
+    const float a = vj.at[chain], an = vj.at_next[chain];
+    c1 = sqrtf(1.0f - a); c2 = sqrtf(a); c3 = sqrtf(an); c4 = sqrtf(1.0f - an);
+  }
 #pragma unroll
   for (int fa = 0; fa < FR; ++fa)
 #pragma unroll
@@ -112,6 +126,15 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
         if (EPI == EPI_GRAD) {
           v = -(2.0f * v);
           if (aux_img) v = v * nhmc_in1(aux_img[off]);
+        }
+        if (EPI == EPI_VJP) {                              // same op order as k_mix_bwd<false,false>, final_clip = 1
+          const float ee = e_img[off];
+          const float u = (aux_img[off] - ee * c1) / c2;
+          float gin = -(2.0f * v);
+          gin = gin * nhmc_in1(c3 * nhmc_clip1(u) + c4 * ee);
+          const float gu = ((gin * c3) * nhmc_in1(u)) / c2;
+          ge_img[off] = c4 * gin + (-gu) * c1;
+          v = gu;
         }
         out_img[off] = v;
       }
@@ -135,22 +158,22 @@ int tile_of2(int R, int C) { return (R % 128 == 0 && C % 128 == 0) ? 128 : ((R %
 // OUT[R][C] = IN[K][R]^T * S[K][C] per image; K % 32 == 0, R % 32 == 0, C % 32 == 0.
 template <int EPI, bool PRECLIP>
 int gemm_krc(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
-             int channels, int K, int R, int C, hipStream_t st) {
+             int channels, int K, int R, int C, hipStream_t st, VjpArgs vj = VjpArgs{}) {
   const int T = tile_of2(R, C);
   dim3 grid(C / T, R / T, n_img);
   if (T == 128)
-    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels);
+    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   else if (T == 64)
-    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels);
+    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   else
-    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels);
+    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   return nhmc_launch_status();
 }
 
 template <int EPI, bool PRECLIP>
 int gemm(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
-         int channels, int d, hipStream_t st) {
-  return gemm_krc<EPI, PRECLIP>(IN, S, OUT, Dmap, aux, ws, n_img, channels, d, d, d, st);
+         int channels, int d, hipStream_t st, VjpArgs vj = VjpArgs{}) {
+  return gemm_krc<EPI, PRECLIP>(IN, S, OUT, Dmap, aux, ws, n_img, channels, d, d, d, st, vj);
 }
 
 int tile_of(int d) { return d % 128 == 0 ? 128 : (d % 64 == 0 ? 64 : 32); }
@@ -214,6 +237,37 @@ extern "C" int nhmc_data_spectral(const float* xt, const float* y, const float* 
   if ((rc = gemm<EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
   if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
   return gemm<EPI_GRAD, false>(A, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, dim, st);
+}
+
+// Data term + VJP of the last DDIM step for the spectral operator: xt_next = the clipped decode (what k_mix_fwd with
+// final_clip wrote), (xt, e) the step's inputs.  The eighth product's epilogue writes g_xt and g_e directly.
+extern "C" int nhmc_data_spectral_vjp(const float* xt_next, const float* y, const float* factors, const float* Dmap,
+                                      const float* xt, const float* e, int e_channels, const float* at,
+                                      const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
+                                      int n_chains, int channels, int dim, nhmc_stream_t stream) {
+  if (!xt_next || !y || !factors || !Dmap || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
+    return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim) || (e_channels != channels && e_channels != 2 * channels)) return NHMC_ERR_SHAPE;
+  const int64_t dd = (int64_t)dim * dim;
+  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(tmp))
+    return NHMC_ERR_ALIGN;
+  const float *U1 = factors, *U2 = factors + dd, *V1 = factors + 2 * dd, *V2 = factors + 3 * dd;
+  const float *U1T = U1 + 4 * dd, *U2T = U1 + 5 * dd, *V1T = U1 + 6 * dd, *V2T = U1 + 7 * dd;
+  hipStream_t st = nhmc_s(stream);
+  const int n = n_chains * channels;
+  float* A = tmp;
+  float* B = tmp + (int64_t)n * dd;
+  int rc;
+  if ((rc = gemm<EPI_NONE, false>(xt_next, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_RESID, false>(A, U2T, B, nullptr, y, loss_ws, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_NONE, false>(B, U1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  const VjpArgs vj{e, g_e, at, at_next, e_channels};
+  return gemm<EPI_VJP, false>(A, V2T, g_xt, nullptr, xt, nullptr, n, channels, dim, st, vj);
 }
 
 // ---- separable strided convolution (SRConv, obs_functions/Hfuncs.py:527-607) ----------------------------------

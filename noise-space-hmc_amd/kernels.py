@@ -365,6 +365,26 @@ def data_spectral(xt, y, factors, Dmap, apply_clip=True):
     return sum_partials(ws, tiles, B), g
 
 
+def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None):
+    """Spectral data term on the clipped decode `xt_next` + VJP of the last DDIM step (inputs xt, e) in the last
+    product's epilogue -> (loss [B] float64, g_xt, g_e)."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    dim = xt.shape[2]
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    tiles = lib.nhmc_spectral_tiles(Cc, dim)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)          # channels [0, C) are written
+    rc = lib.nhmc_data_spectral_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'),
+                                    _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32),
+                                    _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                    _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    _lib.check(rc, 'nhmc_data_spectral_vjp')
+    return sum_partials(ws, tiles, B), g_xt, g_e
+
+
 # ---- a5-a7 ----------------------------------------------------------------------------------
 def hamiltonian(sums_ws, n_elem, loss, sigma_y, m_inv, want_terms=False):
     lib = _lib.load()

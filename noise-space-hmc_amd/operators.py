@@ -189,6 +189,16 @@ class Deblurring2D(H_functions):
     def data_term(self, xt, y, apply_clip=True):
         return K.data_spectral(xt, y.reshape(xt.shape).contiguous(), self.factors, self.Dmap, apply_clip)
 
+    fused_wants_decode = True              # the engine hands over the clipped decode it already holds
+
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None):
+        """Data term + VJP of the last DDIM step (applied in the last product's epilogue) -> (loss, g_xt, g_e).
+        xt_next: the clipped decode of that step (recomputed when the caller does not have it)."""
+        if xt_next is None:
+            xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
+        return K.data_spectral_vjp(xt_next, y.reshape(xt_in.shape).contiguous(), self.factors, self.Dmap, xt_in, e, at,
+                                   at_next, g_e_out=g_e_out)
+
 
 class Deblurring(Deblurring2D):
     """obs_functions/Hfuncs.py:236-316 (`deblur_gauss`): the same spectral form with one 1-D kernel on both

@@ -197,8 +197,9 @@ class LeapfrogEngine:
         for s in reversed(range(S)):
             leaf, e_c = ins[s]
             if fused and s == S - 1:                  # data term + last-step VJP in one kernel
+                extra = dict(xt_next=cur) if getattr(self.operator, 'fused_wants_decode', False) else {}
                 l, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, self.at[s].expand(n),
-                                                                self.at_next[s].expand(n), y, g_e_out=bufs[s])
+                                                                self.at_next[s].expand(n), y, g_e_out=bufs[s], **extra)
                 loss_out.copy_(l)
             else:
                 g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),

@@ -90,3 +90,47 @@ def test_engine_sr_with_and_without_fusion_agree(tiny_score):
     b = eng.decode_and_grad(x, y)
     for u, v in zip(a, b):
         assert torch.equal(u, v) or float((u - v).abs().max()) <= 1e-12 * float(v.abs().max())
+
+
+@pytest.mark.parametrize('dim,B', [(32, 2), (64, 3), (256, 2)])
+def test_fused_spectral_last_vjp_equals_two_kernel_path(dim, B):
+    """The VJP applied in the last product's epilogue = data term (apply_clip = 0 on the clipped decode) followed by
+    k_mix_bwd(final_clip = 1): the same MFMA accumulators go through the same scalar op order, hence the same bits."""
+    import nhmc.kernels as K
+    from nhmc import operators
+    g_ = torch.Generator().manual_seed(dim)
+    op = operators.build_operator('deblur_aniso', 3, dim, torch.device('cuda'))
+    xt = (torch.randn(B, 3, dim, dim, generator=g_) * 0.5).cuda()
+    e = torch.randn(B, 6, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    b = osched.betas_fp32()
+    at = osched.alpha_bar(b, torch.full((B,), 250)).cuda()
+    atn = osched.alpha_bar(b, torch.full((B,), -1)).cuda()
+    cur = K.ddim_mix_fwd(xt, e, at, atn, final_clip=True)['xt_next']
+    loss_a, g = op.data_term(cur, y, apply_clip=False)
+    gx_a, ge_a = K.ddim_mix_bwd(g, xt, e, at, atn, final_clip=True)
+    loss_b, gx_b, ge_b = op.fused_last_vjp(xt, e, at, atn, y, xt_next=cur)
+    assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b)
+    assert torch.equal(loss_a, loss_b)
+    loss_c, gx_c, _ = op.fused_last_vjp(xt, e, at, atn, y)            # decode recomputed inside
+    assert torch.equal(gx_a, gx_c) and torch.equal(loss_a, loss_c)
+    buf = torch.full_like(e, 7.0)
+    op.fused_last_vjp(xt, e, at, atn, y, g_e_out=buf, xt_next=cur)
+    assert torch.equal(buf[:, :3], ge_a[:, :3]) and bool((buf[:, 3:] == 7.0).all())
+
+
+@pytest.mark.parametrize('deg', ['deblur_aniso', 'deblur_gauss'])
+def test_engine_spectral_with_and_without_fusion_agree(tiny_score, deg):
+    from nhmc import operators, plugin, sampler
+    dim, B = 32, 3
+    g_ = torch.Generator().manual_seed(13)
+    op = operators.build_operator(deg, 3, dim, torch.device('cuda'))
+    algo = plugin.HMC(copy.deepcopy(tiny_score).cuda(), op, 0.1)
+    eng = sampler.LeapfrogEngine(algo.score, op, osched.betas_fp32().cuda(), SEQ, SEQ_NEXT, torch.device('cuda'))
+    x = torch.randn(B, 3, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    a = eng.decode_and_grad(x, y)
+    eng.fuse_last = False
+    b = eng.decode_and_grad(x, y)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

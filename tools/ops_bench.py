@@ -46,3 +46,10 @@ an = torch.ones(B, device=dev)
 for name, o, yy in (('inpaint', opi, yi), ('sr4', op4, y4), ('sr16', op16, y16)):
     ms = timeit(lambda: o.fused_last_vjp(x, e6, at, an, yy, g_e_out=ge))
     print(f'{name} fused last VJP B={B}: {ms*1e3:.1f} us  {(4*T)/ms/1e6:.0f} GB/s (4T)')
+cur = K.ddim_mix_fwd(x, e6, at, an, final_clip=True)['xt_next']
+def two_kernel():
+    l, g = op.data_term(cur, y, apply_clip=False)
+    return K.ddim_mix_bwd(g, x, e6, at, an, final_clip=True, g_e_out=ge)
+ms2 = timeit(two_kernel, 10)
+ms1 = timeit(lambda: op.fused_last_vjp(x, e6, at, an, y, g_e_out=ge, xt_next=cur), 10)
+print(f'aniso data term + last VJP B={B}: two kernels {ms2*1e3:.1f} us, fused epilogue {ms1*1e3:.1f} us')
