@@ -128,7 +128,8 @@ def hot_path_only(device, prob, B, steps):
         g2 = None
         for s in (2, 1, 0):
             if s == 2 and hasattr(op, 'fused_last_vjp'):            # data term fused into the last-step VJP
-                loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y, g_e_out=ge[s])
+                extra = dict(xt_next=cur) if getattr(op, 'fused_wants_decode', False) else {}
+                loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y, g_e_out=ge[s], **extra)
             elif s == 2:
                 loss, g = op.data_term(cur, y, apply_clip=False)
                 g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], final_clip=True, g_e_out=ge[s])
