@@ -100,11 +100,23 @@ def leapfrog_roofline(device, B, launches):
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     alg_bytes = 5 * B * N * 4                                        # R x,p,g + W x,p  (20 B/element)
-    del sets
+    # copy ceiling: a plain streaming copy with the same access pattern over the same rotating buffers
+    flat = [t for s in sets for t in s]
+    for i in range(len(flat)):
+        K.copy_probe(flat[i], flat[(i + 1) % len(flat)])
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(launches):
+        K.copy_probe(flat[i % len(flat)], flat[(i + 4) % len(flat)])
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * B * N * 4 / (e0.elapsed_time(e1) * 1e-3 / launches) / 1e9
+    del sets, flat
     torch.cuda.empty_cache()
     return dict(kernel='k_leapfrog<MID> (nhmc_leapfrog_fused)', avg_us=avg_s * 1e6, bytes_per_launch=alg_bytes,
                 achieved=alg_bytes / avg_s / 1e9, launches=launches, buffer_sets=R,
-                footprint_mib=R * per_set / 2 ** 20)
+                footprint_mib=R * per_set / 2 ** 20, copy_ceiling_gbs=copy_gbs,
+                frac_of_copy_ceiling=alg_bytes / avg_s / 1e9 / copy_gbs)
 
 
 def hot_path_only(device, prob, B, steps):

@@ -317,6 +317,13 @@ int nhmc_randn_philox(float* out, uint64_t seed, uint32_t chain_id0, uint32_t dr
 int nhmc_uniform_philox(float* out, uint64_t seed, uint32_t chain_id0, uint32_t draw,
                         int n_chains, nhmc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * (d) Measurement aid: a streaming copy dst = src with the access pattern of the fused update (256-thread blocks,
+ *     one non-temporal float4 per thread): the "copy ceiling" bench.py quotes beside the 8 TB/s HBM peak
+ *     (SURVEY.md section 8d).  n_elem % 4 == 0, 16-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_copy_probe(const float* src, float* dst, int64_t n_elem, nhmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

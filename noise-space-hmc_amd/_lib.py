@@ -62,6 +62,7 @@ SIGNATURES = {
     'nhmc_schedule_begin_mass': (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     'nhmc_psnr': (I, [P, P, P, P, I, I64, P]),
     'nhmc_randn_philox': (I, [P, U64, U32, U32, F, I, I64, P]),
+    'nhmc_copy_probe': (I, [P, P, I64, P]),
     'nhmc_uniform_philox': (I, [P, U64, U32, U32, I, P]),
 }
 

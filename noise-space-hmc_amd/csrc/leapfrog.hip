@@ -84,6 +84,12 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
   }
 }
 
+__global__ __launch_bounds__(NHMC_BLOCK) void k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                           int64_t n4) {
+  const int64_t q = (int64_t)blockIdx.x * NHMC_BLOCK + threadIdx.x;
+  if (q < n4) nhmc_stnt(&dst[q], nhmc_ldnt(&src[q]));
+}
+
 template <int MODE>
 int launch(float* x, float* p, const float* g, const float* g2, const double* eps, const double* sigma_y,
            double m_inv, int n_chains, int64_t n_elem, double* ws, hipStream_t st) {
@@ -125,4 +131,14 @@ extern "C" int nhmc_leapfrog_fused(int mode, float* x, float* p, const float* g,
     case NHMC_LF_LAST:  return launch<NHMC_LF_LAST>(x, p, g, g2, eps, sigma_y, m_inv, n_chains, n_elem, sums_ws, st);
     default: return NHMC_ERR_ARG;
   }
+}
+
+extern "C" int nhmc_copy_probe(const float* src, float* dst, int64_t n_elem, nhmc_stream_t stream) {
+  if (!src || !dst || n_elem <= 0) return NHMC_ERR_ARG;
+  if ((n_elem & 3) || !nhmc_aligned16(src) || !nhmc_aligned16(dst)) return NHMC_ERR_ALIGN;
+  const int64_t n4 = n_elem / 4, blocks = (n4 + NHMC_BLOCK - 1) / NHMC_BLOCK;
+  if (blocks > 0x7fffffff) return NHMC_ERR_SHAPE;
+  NHMC_LAUNCH(k_copy_probe, dim3((unsigned)blocks), dim3(NHMC_BLOCK), 0, nhmc_s(stream), (const float4*)src,
+              (float4*)dst, n4);
+  return nhmc_launch_status();
 }

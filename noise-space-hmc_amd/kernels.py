@@ -522,3 +522,13 @@ def uniform_philox(n_chains, seed, chain_id0, draw, device='cuda'):
     _lib.check(lib.nhmc_uniform_philox(_p(out), int(seed), int(chain_id0), int(draw), n_chains, _stream()),
                'nhmc_uniform_philox')
     return out
+
+
+def copy_probe(src, dst):
+    """Streaming copy with the fused update's access pattern (measurement aid for bench.py's copy ceiling)."""
+    lib = _lib.load()
+    if src.numel() != dst.numel():
+        raise _lib.NhmcError('copy_probe: size mismatch')
+    _lib.check(lib.nhmc_copy_probe(_p(src, torch.float32, 'src'), _p(dst, torch.float32, 'dst'), src.numel(), _stream()),
+               'nhmc_copy_probe')
+    return dst

@@ -58,3 +58,16 @@ def test_frozen_chains_do_not_move(tiny_score):
     assert torch.equal(got['x_prop'][1], dx[1]) and not torch.equal(got['x_prop'][0], dx[0])
     acc, _ = K.metropolis(got['H0'], got['H1'], torch.zeros(3, device='cuda'), st['active'])
     assert int(acc[1]) == 0
+
+
+def test_copy_probe_copies_and_checks_alignment():
+    import nhmc.kernels as K
+    from nhmc import _lib
+    src = torch.randn(3, 1000, device='cuda')                     # 3000 elements: a ragged last block
+    dst = torch.zeros_like(src)
+    assert torch.equal(K.copy_probe(src, dst), src)
+    flat = torch.randn(4001, device='cuda')
+    with pytest.raises(_lib.NhmcError):
+        K.copy_probe(flat[1:], torch.zeros(4000, device='cuda'))  # misaligned source
+    with pytest.raises(_lib.NhmcError):
+        K.copy_probe(flat[:3998].contiguous(), torch.zeros(3998, device='cuda'))   # n % 4 != 0
