@@ -100,7 +100,7 @@ def leapfrog_roofline(device, B, launches):
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     alg_bytes = 5 * B * N * 4                                        # R x,p,g + W x,p  (20 B/element)
-    # copy ceiling: a plain streaming copy with the same access pattern over the same rotating buffers
+    # measured copy-kernel bandwidth: a plain streaming copy with the same access pattern, same buffers
     flat = [t for s in sets for t in s]
     for i in range(len(flat)):
         K.copy_probe(flat[i], flat[(i + 1) % len(flat)])
@@ -115,8 +115,9 @@ def leapfrog_roofline(device, B, launches):
     torch.cuda.empty_cache()
     return dict(kernel='k_leapfrog<MID> (nhmc_leapfrog_fused)', avg_us=avg_s * 1e6, bytes_per_launch=alg_bytes,
                 achieved=alg_bytes / avg_s / 1e9, launches=launches, buffer_sets=R,
-                footprint_mib=R * per_set / 2 ** 20, copy_ceiling_gbs=copy_gbs,
-                frac_of_copy_ceiling=alg_bytes / avg_s / 1e9 / copy_gbs)
+                footprint_mib=R * per_set / 2 ** 20, copy_kernel_gbs=copy_gbs,
+                frac_of_copy_kernel=alg_bytes / avg_s / 1e9 / copy_gbs,
+                copy_note='nhmc_copy_probe: 1 read : 1 write streaming copy, same buffers; the update is 3 reads : 2 writes')
 
 
 def hot_path_only(device, prob, B, steps):
