@@ -21,7 +21,8 @@ from collections import defaultdict
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
 OURS = ('k_leapfrog', 'k_mix_', 'k_map_back', 'k_data_inpaint', 'k_inpaint', 'k_sr', 'k_sgemm', 'k_sum_partials',
-        'k_hamiltonian', 'k_metropolis', 'k_schedule', 'k_accept_commit', 'k_psnr', 'k_randn', 'k_uniform')
+        'k_hamiltonian', 'k_metropolis', 'k_schedule', 'k_accept_commit', 'k_psnr', 'k_randn', 'k_uniform',
+        'k_color', 'k_fwht', 'k_cs_', 'k_copy_probe', 'k_latent', 'k_mass', 'k_rank')
 
 
 def short(name):
@@ -75,4 +76,24 @@ if acc:
                            'hbm_bytes_per_launch': (2 * fe + wr) * 1024,
                            'note': 'FETCH_SIZE doubled (gfx950 wide-read correction), separate --pmc passes, source ' + tag},
                           open(os.path.join(here, 'traffic_leapfrog.json'), 'w'), indent=1)
+
+# operator pass (tools/profile_ops.sh -> gpurun_out/prof_ops_rNN): python profiles/summarize.py gpurun_out/prof_ops_r01 r01
+p = one('stats/*/*_kernel_stats.csv')
+if p:
+    stats(p, os.path.join(here, f'{tag}_kernel_stats_ops.csv'), lambda r: any(k in r['Name'] for k in OURS))
+cols = ['SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES']
+ops = defaultdict(lambda: defaultdict(list))
+for sub in ('pmc_lds', 'pmc_mfma'):
+    p = one(f'{sub}/*/*_counter_collection.csv')
+    if not p:
+        continue
+    for r in csv.DictReader(open(p)):
+        if r['Counter_Name'] in cols and any(k in r['Kernel_Name'] for k in OURS):
+            ops[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+if ops:
+    with open(os.path.join(here, f'{tag}_pmc_ops.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel (tools/ops_bench.py 16: B=16, 3x256x256)'] + cols)
+        for k, d in sorted(ops.items()):
+            w.writerow([k[:110]] + [f'{sum(d[c]) / len(d[c]):.0f}' if d[c] else '' for c in cols])
 print('ok')
