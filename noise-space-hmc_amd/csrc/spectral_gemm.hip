@@ -39,8 +39,9 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
   constexpr int NT = 64 * NW * NW;
   constexpr int FR = T / (32 * NW);
   constexpr int NV = (BK * T / 4) / NT;          // float4 per thread per operand tile
-  __shared__ float As[BK * T];
-  __shared__ float Bs[BK * T];
+  __shared__ float L[2 * BK * T];        // operand tiles in the main loop, one accumulator row-slab in the epilogue
+  float* const As = L;
+  float* const Bs = L + BK * T;
 
   const int img = blockIdx.z, tr = blockIdx.y * T, tc = blockIdx.x * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,9 +90,12 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  // Wave-uniform image bases + one 32-bit per-lane offset: 64-bit per-element addresses for three arrays cost
-  // ~90 VGPRs and halved the occupancy of the MULD / RESID / GRAD variants.
+  // ---- epilogue ----
+  // C/D map of the 32x32 MFMA tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators go through
+  // LDS one row-slab (T/NW rows x T columns <= the 2*BK*T floats of the operand tiles) at a time, so that every
+  // global access of the epilogue -- the store and the Dmap / y / xt / e reads of the fused variants -- is a 16-byte
+  // row access (the direct per-lane 4-byte form cost 45 us in the VJP variant, as much as the kernel it replaced).
+  static_assert((T / NW) * T <= 2 * BK * T, "accumulator slab must fit the operand tiles");
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * R * C;
   const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * R * C : nullptr;
@@ -109,40 +113,63 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
     const float a = vj.at[chain], an = vj.at_next[chain];
     c1 = sqrtf(1.0f - a); c2 = sqrtf(a); c3 = sqrtf(an); c4 = sqrtf(1.0f - an);
   }
+  constexpr int SLAB_V = ((T / NW) * T / 4) / NT;       // float4 per thread per slab
+  for (int h = 0; h < NW; ++h) {
+    if (wi == h) {
 #pragma unroll
-  for (int fa = 0; fa < FR; ++fa)
+      for (int fa = 0; fa < FR; ++fa)
 #pragma unroll
-    for (int fb = 0; fb < FR; ++fb) {
-      const int base = (tr + (wi * FR + fa) * 32 + 4 * lh) * C + tc + (wj * FR + fb) * 32 + lr;
+        for (int fb = 0; fb < FR; ++fb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int off = base + ((r & 3) + 8 * (r >> 2)) * C;
-        float v = acc[fa][fb][r];
-        if (EPI == EPI_MULD) v = v * dm_img[off];
-        if (EPI == EPI_RESID) {
-          v = aux_img[off] - v;                           // r = y - H x
-          lsum += v * v;
+          for (int r = 0; r < 16; ++r)
+            L[(fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * T + (wj * FR + fb) * 32 + lr] = acc[fa][fb][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < SLAB_V; ++v) {
+      const int idx = tid + v * NT, row = idx / (T / 4), c4i = idx % (T / 4);
+      const int off = (tr + h * (T / NW) + row) * C + tc + c4i * 4;
+      nhmc_v4f q = *reinterpret_cast<const nhmc_v4f*>(&L[row * T + c4i * 4]);
+      if (EPI == EPI_MULD) {
+        const nhmc_v4f d = *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
+        q = q * d;
+      }
+      if (EPI == EPI_RESID) {
+        const nhmc_v4f yv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+        q = yv - q;                                       // r = y - H x
+        lsum += q.x * q.x; lsum += q.y * q.y; lsum += q.z * q.z; lsum += q.w * q.w;
+      }
+      if (EPI == EPI_GRAD) {
+        q = -(2.0f * q);
+        if (aux_img) {
+          const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+          q.x = q.x * nhmc_in1(xv.x); q.y = q.y * nhmc_in1(xv.y); q.z = q.z * nhmc_in1(xv.z); q.w = q.w * nhmc_in1(xv.w);
         }
-        if (EPI == EPI_GRAD) {
-          v = -(2.0f * v);
-          if (aux_img) v = v * nhmc_in1(aux_img[off]);
-        }
-        if (EPI == EPI_VJP) {                              // same op order as k_mix_bwd<false,false>, final_clip = 1
-          const float ee = e_img[off];
-          const float u = (aux_img[off] - ee * c1) / c2;
-          float gin = -(2.0f * v);
+      }
+      if (EPI == EPI_VJP) {                               // same op order as k_mix_bwd<false,false>, final_clip = 1
+        const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+        const nhmc_v4f ev = *reinterpret_cast<const nhmc_v4f*>(&e_img[off]);
+        nhmc_v4f ge;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const float ee = ev[k4];
+          const float u = (xv[k4] - ee * c1) / c2;
+          float gin = -(2.0f * q[k4]);
           gin = gin * nhmc_in1(c3 * nhmc_clip1(u) + c4 * ee);
           const float gu = ((gin * c3) * nhmc_in1(u)) / c2;
-          ge_img[off] = c4 * gin + (-gu) * c1;
-          v = gu;
+          ge[k4] = c4 * gin + (-gu) * c1;
+          q[k4] = gu;
         }
-        out_img[off] = v;
+        *reinterpret_cast<nhmc_v4f*>(&ge_img[off]) = ge;
       }
+      *reinterpret_cast<nhmc_v4f*>(&out_img[off]) = q;
     }
+    __syncthreads();                                      // the slab is rewritten by the next row of waves
+  }
   if (EPI == EPI_RESID) {
     __shared__ double red[NW * NW];
-    double s = nhmc_wave_sum((double)lsum);
-    if (lane == 0) red[wave] = s;
+    double sw = nhmc_wave_sum((double)lsum);
+    if (lane == 0) red[wave] = sw;
     __syncthreads();
     if (tid == 0) {
       double tot = 0.0;
