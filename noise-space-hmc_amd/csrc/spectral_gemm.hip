@@ -43,7 +43,15 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
   float* const As = L;
   float* const Bs = L + BK * T;
 
-  const int img = blockIdx.z, tr = blockIdx.y * T, tc = blockIdx.x * T;
+  // 1-D grid, XCD-aware: hardware block id L runs on XCD L % 8, so the blocks of one XCD are made consecutive in
+  // the logical order [image][tile row][tile col] -- the tiles of an image (which share its k-slabs pairwise, and all
+  // share S) then fill the same L2 instead of four different ones.
+  const int tiles_c = C / T, tiles_img = (R / T) * tiles_c;
+  const int total = gridDim.x;
+  int logical = blockIdx.x;
+  if ((total & 7) == 0) logical = (logical & 7) * (total >> 3) + (logical >> 3);
+  const int img = logical / tiles_img, tile = logical % tiles_img;
+  const int tr = (tile / tiles_c) * T, tc = (tile % tiles_c) * T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / NW, wj = wave % NW;
   const int lr = lane & 31, lh = lane >> 5;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
       double tot = 0.0;
       for (int w = 0; w < NW * NW; ++w) tot += red[w];
       // tiles of one chain are contiguous: [chain][channel][tile_row][tile_col]
-      ws[((int64_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
+      ws[(int64_t)img * tiles_img + tile] = tot;
     }
   }
 }
@@ -187,7 +195,7 @@ template <int EPI, bool PRECLIP>
 int gemm_krc(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
              int channels, int K, int R, int C, hipStream_t st, VjpArgs vj = VjpArgs{}) {
   const int T = tile_of2(R, C);
-  dim3 grid(C / T, R / T, n_img);
+  dim3 grid((unsigned)((C / T) * (R / T) * n_img));
   if (T == 128)
     NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   else if (T == 64)
