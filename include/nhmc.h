@@ -217,6 +217,12 @@ int nhmc_srconv_tiles(int channels, int small_dim);
 int nhmc_data_srconv(const float* xt, const float* y, const float* At, const float* A, int apply_clip,
                      float* g_xt, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
                      int small_dim, nhmc_stream_t stream);
+/* nhmc_data_srconv on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the final
+ * product's epilogue (as nhmc_data_spectral_vjp): writes g_xt and channels [0, channels) of g_e. */
+int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* At, const float* A, const float* xt,
+                         const float* e, int e_channels, const float* at, const float* at_next, float* g_xt,
+                         float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim, int small_dim,
+                         nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a5  Hamiltonian                          main_sampling.py:697,717-718

@@ -49,6 +49,7 @@ SIGNATURES = {
     'nhmc_sandwich_rect': (I, [P, P, P, P, P, I, I, I, I, I, P]),
     'nhmc_srconv_tiles': (I, [I, I]),
     'nhmc_data_srconv': (I, [P, P, P, P, I, P, P, P, I, I, I, I, P]),
+    'nhmc_data_srconv_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P]),
     'nhmc_hamiltonian': (I, [P, I, P, P, D, P, P, I, P]),
     'nhmc_metropolis': (I, [P, P, P, P, P, P, I, P]),
     'nhmc_schedule_begin': (I, [P, P, P, P, P, P, D, I, I, I, P]),

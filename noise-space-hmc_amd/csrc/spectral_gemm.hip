@@ -285,7 +285,7 @@ extern "C" int nhmc_data_spectral_vjp(const float* xt_next, const float* y, cons
   if (bad(n_chains, channels, dim) || (e_channels != channels && e_channels != 2 * channels)) return NHMC_ERR_SHAPE;
   const int64_t dd = (int64_t)dim * dim;
   if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
-      !nhmc_aligned16(tmp))
+      !nhmc_aligned16(tmp) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_e) || !nhmc_aligned16(Dmap))
     return NHMC_ERR_ALIGN;
   const float *U1 = factors, *U2 = factors + dd, *V1 = factors + 2 * dd, *V2 = factors + 3 * dd;
   const float *U1T = U1 + 4 * dd, *U2T = U1 + 5 * dd, *V1T = U1 + 6 * dd, *V2T = U1 + 7 * dd;
@@ -351,4 +351,30 @@ extern "C" int nhmc_data_srconv(const float* xt, const float* y, const float* At
   if ((rc = gemm_krc<EPI_RESID, false>(T1, At, Rr, nullptr, y, loss_ws, n, channels, d, sd, sd, st))) return rc;   // r = y - A X A^T
   if ((rc = gemm_krc<EPI_NONE, false>(Rr, A, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;  // r^T A
   return gemm_krc<EPI_GRAD, false>(T2, A, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, sd, d, d, st);  // A^T r A
+}
+
+// Same with the VJP of the last DDIM step applied in the last product's epilogue (xt_next = the clipped decode).
+extern "C" int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* At, const float* A,
+                                    const float* xt, const float* e, int e_channels, const float* at,
+                                    const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
+                                    int n_chains, int channels, int dim, int small_dim, nhmc_stream_t stream) {
+  if (!xt_next || !y || !At || !A || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
+    return NHMC_ERR_ARG;
+  if (n_chains <= 0 || channels <= 0 || (int64_t)n_chains * channels > 65535 || (dim % 32) || (small_dim % 32) ||
+      dim <= 0 || small_dim <= 0 || (e_channels != channels && e_channels != 2 * channels))
+    return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y) || !nhmc_aligned16(At) || !nhmc_aligned16(A) ||
+      !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e) || !nhmc_aligned16(tmp))
+    return NHMC_ERR_ALIGN;
+  hipStream_t st = nhmc_s(stream);
+  const int n = n_chains * channels, d = dim, sd = small_dim;
+  float* T1 = tmp;                                    // [d][sd]
+  float* Rr = T1 + (int64_t)n * d * sd;               // [sd][sd]
+  float* T2 = Rr + (int64_t)n * sd * sd;              // [sd][d]
+  int rc;
+  if ((rc = gemm_krc<EPI_NONE, false>(xt_next, At, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc;
+  if ((rc = gemm_krc<EPI_RESID, false>(T1, At, Rr, nullptr, y, loss_ws, n, channels, d, sd, sd, st))) return rc;
+  if ((rc = gemm_krc<EPI_NONE, false>(Rr, A, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;
+  const VjpArgs vj{e, g_e, at, at_next, e_channels};
+  return gemm_krc<EPI_VJP, false>(T2, A, g_xt, nullptr, xt, nullptr, n, channels, sd, d, d, st, vj);
 }

@@ -350,6 +350,25 @@ def data_srconv(xt, y, At, A, apply_clip=True):
     return sum_partials(ws, tiles, B), g
 
 
+def data_srconv_vjp(xt_next, y, At, A, xt, e, at, at_next, g_e_out=None):
+    """Bicubic / strided-convolution data term on the clipped decode + VJP of the last DDIM step in the last product's
+    epilogue -> (loss [B] float64, g_xt, g_e)."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    dim, sd = xt.shape[2], A.shape[0]
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    tiles = lib.nhmc_srconv_tiles(Cc, sd)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    tmp = torch.empty(B * Cc * (2 * dim * sd + sd * sd), dtype=torch.float32, device=xt.device)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)
+    rc = lib.nhmc_data_srconv_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'), _p(At, torch.float32),
+                                  _p(A, torch.float32), _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec,
+                                  _p(at), _p(at_next), _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, sd, _stream())
+    _lib.check(rc, 'nhmc_data_srconv_vjp')
+    return sum_partials(ws, tiles, B), g_xt, g_e
+
+
 def data_spectral(xt, y, factors, Dmap, apply_clip=True):
     """factors: packed [8,d,d] = U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T -> (loss [B] float64, g_xt)"""
     lib = _lib.load()

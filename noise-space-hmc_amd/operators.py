@@ -313,6 +313,14 @@ class SRConv(H_functions):
     def data_term(self, xt, y, apply_clip=True):
         return K.data_srconv(xt, y.contiguous(), self.At, self.A, apply_clip)
 
+    fused_wants_decode = True
+
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None):
+        """Data term + VJP of the last DDIM step (in the last product's epilogue) -> (loss, g_xt, g_e)."""
+        if xt_next is None:
+            xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
+        return K.data_srconv_vjp(xt_next, y.contiguous(), self.At, self.A, xt_in, e, at, at_next, g_e_out=g_e_out)
+
 
 def bicubic_taps(factor, a=-0.5):
     """main_sampling.py:266-279."""
