@@ -160,6 +160,11 @@ int nhmc_sr_Ht(const float* y, float* x, int ratio, float scale, int n_chains, i
 int nhmc_color_tiles(int64_t hw);
 int nhmc_data_color(const float* xt, const float* y, const float* w, int apply_clip, float* g_xt,
                     double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
+/* nhmc_data_color fused with the VJP of the LAST DDIM step (as nhmc_ddim_mix_bwd_inpaint / _sr): writes g_xt and
+ * channels [0, channels) of g_e. */
+int nhmc_ddim_mix_bwd_color(const float* xt, const float* e, int e_channels, const float* at, const float* at_next,
+                            const float* y, const float* w, float* g_xt, float* g_e, double* loss_ws, int n_chains,
+                            int channels, int64_t hw, nhmc_stream_t stream);
 int nhmc_color_H(const float* x, const float* w, float* y, int n_chains, int channels, int64_t hw,
                  nhmc_stream_t stream);
 int nhmc_color_Ht(const float* y, const float* w, float* x, int n_chains, int channels, int64_t hw,

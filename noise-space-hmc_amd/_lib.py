@@ -36,6 +36,7 @@ SIGNATURES = {
     'nhmc_sr_Ht': (I, [P, P, I, F, I, I, I, P]),
     'nhmc_color_tiles': (I, [I64]),
     'nhmc_data_color': (I, [P, P, P, I, P, P, I, I, I64, P]),
+    'nhmc_ddim_mix_bwd_color': (I, [P, P, I, P, P, P, P, P, P, P, I, I, I64, P]),
     'nhmc_color_H': (I, [P, P, P, I, I, I64, P]),
     'nhmc_color_Ht': (I, [P, P, P, I, I, I64, P]),
     'nhmc_cs_tiles': (I, [I, I]),

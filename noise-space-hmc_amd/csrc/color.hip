@@ -73,6 +73,65 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__
   }
 }
 
+// Last DDIM step VJP fused with the colorization data term: the clipped decode of every channel is recomputed from
+// (xt, e) in registers, weighted into the grey value, and the residual goes straight through the step's VJP
+// (same op order as k_mix_fwd + k_color<0> + k_mix_bwd, hence the same bits; -3T of traffic).
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_color(
+    const float4* __restrict__ xt, const float4* __restrict__ e, int e_channels, const float* __restrict__ at,
+    const float* __restrict__ at_next, const float4* __restrict__ yin, float4* __restrict__ g_xt,
+    float4* __restrict__ g_e, W wt, int channels, double* __restrict__ loss_ws, int64_t hw4) {
+  const int chain = blockIdx.y;
+  const int64_t q = (int64_t)blockIdx.x * NHMC_BLOCK + threadIdx.x;
+  const float a = at[chain], an = at_next[chain];
+  const float c1 = sqrtf(1.0f - a), c2 = sqrtf(a), c3 = sqrtf(an), c4 = sqrtf(1.0f - an);
+  float acc = 0.0f;
+  if (q < hw4) {
+    const int64_t xbase = (int64_t)chain * channels * hw4, ebase = (int64_t)chain * e_channels * hw4;
+    float pre[MAXC][4], uu[MAXC][4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < channels) {
+        const float4 xv = nhmc_ldnt(&xt[xbase + (int64_t)c * hw4 + q]), ev = nhmc_ldnt(&e[ebase + (int64_t)c * hw4 + q]);
+        const float* xe = reinterpret_cast<const float*>(&xv);
+        const float* ee = reinterpret_cast<const float*>(&ev);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uu[c][k] = (xe[k] - ee[k] * c1) / c2;
+          pre[c][k] = c3 * nhmc_clip1(uu[c][k]) + c4 * ee[k];
+          s[k] += wt.w[c] * nhmc_clip1(pre[c][k]);
+        }
+      }
+    }
+    const float4 y = nhmc_ldnt(&yin[(int64_t)chain * hw4 + q]);
+    const float r[4] = {y.x - s[0], y.y - s[1], y.z - s[2], y.w - s[3]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += r[k] * r[k];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < channels) {
+        float4 ox, oe;
+        float* gx = reinterpret_cast<float*>(&ox);
+        float* gee = reinterpret_cast<float*>(&oe);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float gin = -(2.0f * r[k]) * wt.w[c];
+          gin = gin * nhmc_in1(pre[c][k]);
+          const float gu = ((gin * c3) * nhmc_in1(uu[c][k])) / c2;
+          gx[k] = gu;
+          gee[k] = c4 * gin + (-gu) * c1;
+        }
+        nhmc_stnt(&g_xt[xbase + (int64_t)c * hw4 + q], ox);
+        nhmc_stnt(&g_e[ebase + (int64_t)c * hw4 + q], oe);
+      }
+    }
+  }
+  __shared__ double red[4];
+  double v[1] = {(double)acc};
+  nhmc_block_sum<1>(v, red);
+  if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
+}
+
 bool bad(int n_chains, int channels, int64_t hw) {
   return n_chains <= 0 || n_chains > 65535 || channels <= 0 || channels > MAXC || hw <= 0 || (hw & 3);
 }
@@ -116,4 +175,20 @@ extern "C" int nhmc_color_Ht(const float* y, const float* w, float* x, int n_cha
   if (bad(n_chains, channels, hw)) return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(x) || !nhmc_aligned16(y)) return NHMC_ERR_ALIGN;
   return launch<2>(nullptr, y, x, w, channels, 0, nullptr, n_chains, hw, nhmc_s(stream));
+}
+
+extern "C" int nhmc_ddim_mix_bwd_color(const float* xt, const float* e, int e_channels, const float* at,
+                                       const float* at_next, const float* y, const float* w, float* g_xt, float* g_e,
+                                       double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream) {
+  if (!xt || !e || !at || !at_next || !y || !w || !g_xt || !g_e || !loss_ws) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, hw) || (e_channels != channels && e_channels != 2 * channels)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(y) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e))
+    return NHMC_ERR_ALIGN;
+  W wt;
+  for (int c = 0; c < MAXC; ++c) wt.w[c] = c < channels ? w[c] : 0.0f;
+  const int64_t hw4 = hw / 4;
+  dim3 grid((unsigned)((hw4 + NHMC_BLOCK - 1) / NHMC_BLOCK), (unsigned)n_chains);
+  NHMC_LAUNCH(k_mix_bwd_color, grid, dim3(NHMC_BLOCK), 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
+              e_channels, at, at_next, (const float4*)y, (float4*)g_xt, (float4*)g_e, wt, channels, loss_ws, hw4);
+  return nhmc_launch_status();
 }

@@ -258,6 +258,22 @@ def data_color(xt, y, w, apply_clip=True):
     return sum_partials(ws, tiles, B), g
 
 
+def ddim_mix_bwd_color(xt, e, at, at_next, y, w, g_e_out=None):
+    """Last-step VJP fused with the colorization data term -> (loss [B] float64, g_xt, g_e)."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    tiles = lib.nhmc_color_tiles(hw)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)
+    wp, keep = _host_w(w)
+    rc = lib.nhmc_ddim_mix_bwd_color(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                     _p(y, torch.float32, 'y'), wp, _p(g_xt), _p(g_e), _p(ws), B, Cc, hw, _stream())
+    _lib.check(rc, 'nhmc_ddim_mix_bwd_color')
+    return sum_partials(ws, tiles, B), g_xt, g_e
+
+
 def color_H(x, w):
     lib = _lib.load()
     B, Cc, hw = x.shape[0], x.shape[1], x[0, 0].numel()

@@ -234,6 +234,10 @@ class Colorization(H_functions):
     def data_term(self, xt, y, apply_clip=True):
         return K.data_color(xt, y, self.w, apply_clip)
 
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
+        """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
+        return K.ddim_mix_bwd_color(xt_in, e, at, at_next, y.contiguous(), self.w, g_e_out=g_e_out)
+
 
 class WalshHadamardCS(H_functions):
     """obs_functions/Hfuncs.py:611-651: y[k*C + c] = (FWHT(x_c)/d)[perm[k]] for k < d^2/ratio; H^T = H^+."""
