@@ -182,6 +182,12 @@ int nhmc_cs_Ht(const float* y, const int32_t* kslot, float* x, float* tmp, int n
 int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslot, int apply_clip, float* g_xt,
                  double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
                  nhmc_stream_t stream);
+/* nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last column
+ * pass: writes g_xt and channels [0, channels) of g_e (the caller keeps the sigma-channels zero). */
+int nhmc_data_cs_vjp(const float* xt_next, const float* y, const int32_t* kslot, const float* xt, const float* e,
+                     int e_channels, const float* at, const float* at_next, float* g_xt, float* g_e,
+                     double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
+                     nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a15  Spectral (anisotropic-blur) operator   Hfuncs.py:448-523

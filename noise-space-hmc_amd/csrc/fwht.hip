@@ -19,7 +19,26 @@
 namespace {
 
 enum { PRO_NONE = 0, PRO_CLIP = 1, PRO_GATHER = 2 };
-enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_RESID = 2, EPI_GRAD = 3 };
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4 };
+// EPI_VJP: the gradient goes straight through the VJP of the last DDIM step (k_mix_bwd with final_clip = 1); `xt` is then
+// the step's input and e / g_e are [chain][e_channels][d][d]
+struct VjpArgs { const float* e; float* g_e; const float* at; const float* at_next; int e_channels; };
+struct VjpCoef { float c1, c2, c3, c4; };
+__device__ __forceinline__ VjpCoef vjp_coef(const VjpArgs& vj, int64_t chain) {
+  const float a = vj.at[chain], an = vj.at_next[chain];
+  VjpCoef k;
+  k.c1 = sqrtf(1.0f - a); k.c2 = sqrtf(a); k.c3 = sqrtf(an); k.c4 = sqrtf(1.0f - an);
+  return k;
+}
+// one element: data-term value v (already scaled) -> (g_xt, g_e), same op order as k_mix_bwd<false,false>
+__device__ __forceinline__ void vjp_elem(const VjpCoef& k, float v, float x, float ee, float& gx, float& ge) {
+  const float u = (x - ee * k.c1) / k.c2;
+  float gin = -(2.0f * v);
+  gin = gin * nhmc_in1(k.c3 * nhmc_clip1(u) + k.c4 * ee);
+  const float gu = ((gin * k.c3) * nhmc_in1(u)) / k.c2;
+  gx = gu;
+  ge = k.c4 * gin + (-gu) * k.c1;
+}
 
 template <int V> struct Vec;
 template <> struct Vec<1> { typedef float type; };
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
                                                           const float* __restrict__ y, float* __restrict__ y_out,
                                                           const int32_t* __restrict__ kslot, const float* __restrict__ xt,
                                                           double* __restrict__ loss_ws, int d, int pc, int channels,
-                                                          int64_t m, int apply_clip) {
+                                                          int64_t m, int apply_clip, VjpArgs vj) {
   extern __shared__ float tile[];                                   // [d][pc]
   const int64_t plane = blockIdx.y;                                 // chain*channels + c
   const int c0 = blockIdx.x * pc;
@@ -138,6 +157,13 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
       float r = 0.0f;
       if (k >= 0) { r = y[chain * m + (int64_t)k * channels + c] - v; acc += r * r; }
       out[off] = r;                                                 // zero-filled spectrum of the residual
+    } else if (EPI == EPI_VJP) {
+      const VjpCoef k = vjp_coef(vj, chain);
+      const int64_t eoff = (chain * vj.e_channels + c) * (int64_t)d * d + q;
+      float gx, ge;
+      vjp_elem(k, v, xt[off], vj.e[eoff], gx, ge);
+      out[off] = gx;
+      vj.g_e[eoff] = ge;
     } else {
       v = -(2.0f * v);
       if (apply_clip) v = v * nhmc_in1(xt[off]);
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __rest
                                                              const float* __restrict__ y, float* __restrict__ y_out,
                                                              const int32_t* __restrict__ kslot, const float* __restrict__ xt,
                                                              double* __restrict__ loss_ws, int channels, int64_t m,
-                                                             int apply_clip) {
+                                                             int apply_clip, VjpArgs vj) {
   constexpr int D = 256, PC = 64;
   __shared__ nhmc_v4f tile[D * PC / 4];                               // [row][16 column groups]
   const int64_t plane = blockIdx.y;
@@ -228,6 +254,20 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __rest
         r[e] = re;
       }
       *reinterpret_cast<nhmc_v4f*>(&out[off]) = r;
+    } else if (EPI == EPI_VJP) {
+      const VjpCoef kc = vjp_coef(vj, chain);
+      const int64_t eoff = (chain * vj.e_channels + c) * (int64_t)D * D + q;
+      const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&xt[off]);
+      const nhmc_v4f ev = *reinterpret_cast<const nhmc_v4f*>(&vj.e[eoff]);
+      nhmc_v4f gx, ge;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a, b;
+        vjp_elem(kc, val[e], xv[e], ev[e], a, b);
+        gx[e] = a; ge[e] = b;
+      }
+      *reinterpret_cast<nhmc_v4f*>(&out[off]) = gx;
+      *reinterpret_cast<nhmc_v4f*>(&vj.g_e[eoff]) = ge;
     } else {
       nhmc_v4f gq = -(2.0f * val);
       if (apply_clip) {
@@ -273,15 +313,15 @@ int rows(const float* in, const float* y, const int32_t* kslot, float* out, int 
 
 template <int EPI>
 int cols(const float* in, float* out, const float* y, float* y_out, const int32_t* kslot, const float* xt, double* ws,
-         int n_chains, int channels, int dim, int64_t m, int apply_clip, hipStream_t st) {
+         int n_chains, int channels, int dim, int64_t m, int apply_clip, hipStream_t st, VjpArgs vj = VjpArgs{}) {
   const int pc = panel_cols(dim);
   dim3 grid((unsigned)(dim / pc), (unsigned)(n_chains * channels)), block(NHMC_BLOCK);
   if (dim == 256) {
-    NHMC_LAUNCH((k_fwht_cols256<EPI>), grid, block, 0, st, in, out, y, y_out, kslot, xt, ws, channels, m, apply_clip);
+    NHMC_LAUNCH((k_fwht_cols256<EPI>), grid, block, 0, st, in, out, y, y_out, kslot, xt, ws, channels, m, apply_clip, vj);
     return nhmc_launch_status();
   }
   NHMC_LAUNCH((k_fwht_cols<EPI>), grid, block, (size_t)dim * pc * sizeof(float), st, in, out, y, y_out, kslot, xt, ws,
-              dim, pc, channels, m, apply_clip);
+              dim, pc, channels, m, apply_clip, vj);
   return nhmc_launch_status();
 }
 
@@ -325,4 +365,28 @@ extern "C" int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslo
   if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
   if ((rc = rows<PRO_NONE>(B, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
   return cols<EPI_GRAD>(A, g_xt, nullptr, nullptr, nullptr, xt, nullptr, n_chains, channels, dim, m, apply_clip, st);
+}
+
+// nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last column
+// pass: writes g_xt and channels [0, channels) of g_e.
+extern "C" int nhmc_data_cs_vjp(const float* xt_next, const float* y, const int32_t* kslot, const float* xt,
+                                const float* e, int e_channels, const float* at, const float* at_next, float* g_xt,
+                                float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
+                                nhmc_stream_t stream) {
+  if (!xt_next || !y || !kslot || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp || m <= 0)
+    return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim) || dim > 256 || (e_channels != channels && e_channels != 2 * channels))
+    return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(g_e) || !nhmc_aligned16(tmp) || !nhmc_aligned16(kslot))
+    return NHMC_ERR_ALIGN;
+  hipStream_t st = nhmc_s(stream);
+  float* A = tmp;
+  float* B = tmp + (int64_t)n_chains * channels * dim * dim;
+  int rc;
+  if ((rc = rows<PRO_NONE>(xt_next, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
+  if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
+  if ((rc = rows<PRO_NONE>(B, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
+  const VjpArgs vj{e, g_e, at, at_next, e_channels};
+  return cols<EPI_VJP>(A, g_xt, nullptr, nullptr, nullptr, xt, nullptr, n_chains, channels, dim, m, 0, st, vj);
 }

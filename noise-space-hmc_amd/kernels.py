@@ -325,6 +325,25 @@ def data_cs(xt, y, kslot, apply_clip=True):
     return sum_partials(ws, tiles, B), g
 
 
+def data_cs_vjp(xt_next, y, kslot, xt, e, at, at_next, g_e_out=None):
+    """Walsh-Hadamard CS data term on the clipped decode + VJP of the last DDIM step in the last column pass
+    -> (loss [B] float64, g_xt, g_e)."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    dim = xt.shape[2]
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    tiles = lib.nhmc_cs_tiles(Cc, dim)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)
+    rc = lib.nhmc_data_cs_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'), _p(kslot, torch.int32),
+                              _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next), _p(g_xt),
+                              _p(g_e), _p(ws), _p(tmp), B, Cc, dim, y.shape[1], _stream())
+    _lib.check(rc, 'nhmc_data_cs_vjp')
+    return sum_partials(ws, tiles, B), g_xt, g_e
+
+
 def spectral_apply(x, L, R, Dmap, LoT, RoT):
     """out_c = Lo (D_c o (L^T X_c R)) Ro^T ; x: [B,C,d,d]"""
     lib = _lib.load()

@@ -267,6 +267,14 @@ class WalshHadamardCS(H_functions):
     def data_term(self, xt, y, apply_clip=True):
         return K.data_cs(xt, y, self.kslot, apply_clip)
 
+    fused_wants_decode = True
+
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None):
+        """Data term + VJP of the last DDIM step (in the last column pass) -> (loss, g_xt, g_e)."""
+        if xt_next is None:
+            xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
+        return K.data_cs_vjp(xt_next, y.contiguous(), self.kslot, xt_in, e, at, at_next, g_e_out=g_e_out)
+
 
 def strided_conv_matrix(kernel, img_dim, stride):
     """Hfuncs.py:543-553: [img_dim/stride, img_dim] strided 1-D convolution matrix with reflective padding."""

@@ -173,3 +173,22 @@ def test_fused_color_last_vjp_equals_two_kernel_path(dim, B):
     loss_b, gx_b, ge_b = op.fused_last_vjp(xt, e, at, atn, y)
     assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b)
     assert float((loss_a - loss_b).abs().max() / loss_a.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize('dim,B,ratio', [(32, 2, 2), (64, 3, 4), (256, 2, 4)])
+def test_fused_cs_last_vjp_equals_two_kernel_path(dim, B, ratio):
+    import nhmc.kernels as K
+    from nhmc import operators
+    g_ = torch.Generator().manual_seed(dim + ratio)
+    op = operators.build_operator(f'cs{ratio}', 3, dim, torch.device('cuda'), generator=g_)
+    xt = (torch.randn(B, 3, dim, dim, generator=g_) * 0.5).cuda()
+    e = torch.randn(B, 6, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    b = osched.betas_fp32()
+    at = osched.alpha_bar(b, torch.full((B,), 250)).cuda()
+    atn = osched.alpha_bar(b, torch.full((B,), -1)).cuda()
+    cur = K.ddim_mix_fwd(xt, e, at, atn, final_clip=True)['xt_next']
+    loss_a, g = op.data_term(cur, y, apply_clip=False)
+    gx_a, ge_a = K.ddim_mix_bwd(g, xt, e, at, atn, final_clip=True)
+    loss_b, gx_b, ge_b = op.fused_last_vjp(xt, e, at, atn, y, xt_next=cur)
+    assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b) and torch.equal(loss_a, loss_b)
