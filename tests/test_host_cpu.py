@@ -79,6 +79,20 @@ def test_build_operator_covers_the_hot_path_degradations():
         operators.build_operator('deblur_nonlinear', 3, 64, 'cpu')
 
 
+def test_every_operator_offers_the_engine_surface():
+    """data_term (loss + gradient) and fused_last_vjp (data term handed to the last DDIM-step VJP) for every
+    degradation the CLI accepts; operators whose data term works on the clipped decode say so."""
+    import inspect
+    from nhmc import operators
+    for deg in ['sr4', 'sr16', 'sr_bicubic2', 'inpaint_random', 'inpaint_box', 'deblur_aniso', 'deblur_gauss', 'color', 'cs4']:
+        op = operators.build_operator(deg, 3, 64, torch.device('cpu'))
+        assert callable(op.data_term) and callable(op.fused_last_vjp), deg
+        params = inspect.signature(op.fused_last_vjp).parameters
+        assert list(params)[:5] == ['xt_in', 'e', 'at', 'at_next', 'y'] and 'g_e_out' in params, deg
+        assert ('xt_next' in params) == bool(getattr(op, 'fused_wants_decode', False)), deg
+    assert not hasattr(operators.build_operator('sr32', 3, 64, 'cpu'), 'fused_last_vjp')
+
+
 # ---- reference surfaces ---------------------------------------------------------------------------
 def test_plugin_and_sampler_keep_the_reference_signatures():
     from nhmc import plugin, sampler
