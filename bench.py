@@ -277,6 +277,13 @@ def main():
 
     ms_per_step = value = None
     if not args.kernel_only:
+        if world > 1:
+            # the first score-network call on a machine fills MIOpen's on-disk kernel cache (~1 min); let one rank do it
+            # instead of N ranks racing through the same compiles and the same cache files
+            if rank == 0:
+                step(False)
+                torch.cuda.synchronize()
+            sharding.barrier()
         for _ in range(args.warmup):
             step(False)
         sharding.barrier()
@@ -331,7 +338,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]' if args.deg == 'inpaint_random' else 'BASELINE configs[1] with another degradation') +
                                    f': FFHQ 256x256 {args.deg} sigma_0=0.05 tau=1.0 eps=0.05 '
-                                   'timesteps=3, 64 chains per GPU, FFHQ U-Net architecture random-init fp32',
+                                   f'timesteps=3, {B} chains per GPU, FFHQ U-Net architecture random-init fp32',
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
             'roofline': roofline, 'hot_path_only': hot, 'single_chain': single, 'final_gather': gather, 'cpu_baseline': cpu,
