@@ -112,6 +112,15 @@ int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, c
                               float* g_xt, float* g_e, int fill_sigma, double* loss_ws, int n_chains,
                               int channels, int64_t hw, nhmc_stream_t stream);
 
+/* The same for a WHOLE-PIXEL mask (every pixel keeps all its channels or none, as main_sampling.py:290-305 builds them):
+ * mask_words[hw/32] has bit (p % 32) of word p / 32 set when pixel p (row-major) is kept, prefix[hw/32] is the number of
+ * kept pixels before each word, and y index = channels * rank(p) + channel.  Replaces the T-per-chain slot stream by
+ * 16 KB of tables; hw % 32 == 0.  Same bits as nhmc_ddim_mix_bwd_inpaint. */
+int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int e_channels, const float* at,
+                                 const float* at_next, const float* y, const uint32_t* mask_words,
+                                 const int32_t* prefix, int64_t m, float* g_xt, float* g_e, int fill_sigma,
+                                 double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
+
 /* a11 + a12/a14 fused: the same for the super-resolution operator (obs_functions/Hfuncs.py:180-234), ratio in
  * {2,4,8,16}: r = y - blockmean(clip(xt_next)), loss partials (nhmc_sr_tiles(channels, dim, ratio) per chain),
  * gin = -2 r / ratio^2.  Replaces nhmc_data_sr + nhmc_ddim_mix_bwd(final_clip = 1) (same bits, -3T of traffic).

@@ -146,9 +146,14 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
 // xt_next = clip(c3*clip(u) + c4*e) is recomputed in registers (bit-identical to k_mix_fwd), the residual
 // r = y[slot] - xt_next and the upstream gradient gin = -2 r are formed on the fly, so the separate data-term pass
 // (R xt_next, W g) and this kernel's read of g disappear: -3T per leapfrog step and one launch.
+// PX = true: whole-pixel mask (what inpaint_random / inpaint_box build): instead of the dense CHW -> y map (a stream of
+// T per chain, L2-served) the kernel reads one 32-pixel mask word and its exclusive prefix count (16 KB of tables for
+// 256 x 256) and derives y index = channels * rank(pixel) + channel with a popcount.
+template <bool PX>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
     const float4* __restrict__ xt, const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
-    const float* __restrict__ at_next, const float* __restrict__ y, const int4* __restrict__ slot, int64_t m,
+    const float* __restrict__ at_next, const float* __restrict__ y, const int4* __restrict__ slot,
+    const uint32_t* __restrict__ mask_words, const int32_t* __restrict__ prefix, int channels, int64_t hw, int64_t m,
     float4* __restrict__ g_xt, float4* __restrict__ g_e, double* __restrict__ loss_ws, int64_t n4, int fill_sigma) {
   const int chain = blockIdx.y;
   const Coef k = coef(at, at_next, chain);
@@ -161,7 +166,24 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     if (q >= n4) continue;
     const float4 xv = nhmc_ldnt(&xt[base + q]), ev = nhmc_ldnt(&e[ebase + q]);
-    const int4 sv = slot[q];
+    int4 sv;
+    if (PX) {
+      const int64_t el = q * 4;                              // first of 4 consecutive pixels of one channel (hw % 32 == 0)
+      const int ch = (int)(el / hw);
+      const int64_t p0 = el - (int64_t)ch * hw;
+      const uint32_t word = mask_words[p0 >> 5];
+      const int b0 = (int)(p0 & 31);
+      int rank = prefix[p0 >> 5] + __popc(word & ((1u << b0) - 1u));
+      int* so = reinterpret_cast<int*>(&sv);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool kept = (word >> (b0 + c)) & 1u;
+        so[c] = kept ? rank * channels + ch : -1;
+        rank += kept ? 1 : 0;
+      }
+    } else {
+      sv = slot[q];
+    }
     const float* xe = reinterpret_cast<const float*>(&xv);
     const float* ee = reinterpret_cast<const float*>(&ev);
     const int* se = reinterpret_cast<const int*>(&sv);
@@ -372,9 +394,26 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_
       !nhmc_aligned16(g_e))
     return NHMC_ERR_ALIGN;
   dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  NHMC_LAUNCH(k_mix_bwd_inpaint, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
-              (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)slot, m, (float4*)g_xt, (float4*)g_e, loss_ws,
-              n_elem / 4, fill_sigma);
+  NHMC_LAUNCH(k_mix_bwd_inpaint<false>, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
+              (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)slot, (const uint32_t*)nullptr,
+              (const int32_t*)nullptr, channels, hw, m, (float4*)g_xt, (float4*)g_e, loss_ws, n_elem / 4, fill_sigma);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int e_channels, const float* at,
+                                            const float* at_next, const float* y, const uint32_t* mask_words,
+                                            const int32_t* prefix, int64_t m, float* g_xt, float* g_e, int fill_sigma,
+                                            double* loss_ws, int n_chains, int channels, int64_t hw,
+                                            nhmc_stream_t stream) {
+  if (!xt || !e || !at || !at_next || !y || !mask_words || !prefix || !g_xt || !g_e || !loss_ws || m <= 0)
+    return NHMC_ERR_ARG;
+  if (bad_shape(n_chains, channels, hw, e_channels) || (hw & 31)) return NHMC_ERR_SHAPE;
+  const int64_t n_elem = (int64_t)channels * hw;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e)) return NHMC_ERR_ALIGN;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  NHMC_LAUNCH(k_mix_bwd_inpaint<true>, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
+              (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)nullptr, mask_words, prefix, channels, hw, m,
+              (float4*)g_xt, (float4*)g_e, loss_ws, n_elem / 4, fill_sigma);
   return nhmc_launch_status();
 }
 

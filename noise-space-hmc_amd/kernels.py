@@ -146,6 +146,23 @@ def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot, g_e_out=None):
     return sum_partials(ws, tiles, B), g_xt, g_e
 
 
+def ddim_mix_bwd_inpaint_px(xt, e, at, at_next, y, mask_words, prefix, g_e_out=None):
+    """Whole-pixel-mask form of ddim_mix_bwd_inpaint: bit mask + prefix counts instead of the dense slot map."""
+    lib = _lib.load()
+    B, Cc, hw, ec = _mix_shapes(xt, e)
+    at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
+    g_xt = torch.empty_like(xt)
+    g_e = g_e_out if g_e_out is not None else torch.empty_like(e)
+    tiles = leapfrog_tiles(Cc * hw)
+    ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
+    rc = lib.nhmc_ddim_mix_bwd_inpaint_px(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                          _p(y, torch.float32, 'y'), _p(mask_words, torch.int32, 'mask_words'),
+                                          _p(prefix, torch.int32, 'prefix'), y.shape[1], _p(g_xt), _p(g_e),
+                                          int(g_e_out is None), _p(ws), B, Cc, hw, _stream())
+    _lib.check(rc, 'nhmc_ddim_mix_bwd_inpaint_px')
+    return sum_partials(ws, tiles, B), g_xt, g_e
+
+
 def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None):
     """Last-step VJP fused with the super-resolution data term -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()

@@ -63,6 +63,18 @@ class Inpainting(H_functions):
         self.kept_chw = kept_chw.to(torch.int32).to(device)
         self.slot = slot.to(device)
         self._singulars = torch.ones(self.M, device=device)
+        # whole-pixel masks (what main_sampling.py:290-305 builds): bit mask + prefix counts for the fused kernel
+        self.mask_words = self.mask_prefix = None
+        pix = slot.view(channels, hw).t()                                        # [hw, C]
+        kept_px = pix[:, 0] >= 0
+        rank = torch.cumsum(kept_px.to(torch.int64), 0) - 1
+        want = torch.where(kept_px[:, None], rank[:, None] * channels + torch.arange(channels)[None], torch.full_like(pix, -1).long())
+        if hw % 32 == 0 and bool(((pix >= 0) == kept_px[:, None]).all()) and bool((pix.long() == want).all()):
+            bits = kept_px.view(-1, 32).to(torch.int64)
+            words = (bits << torch.arange(32)).sum(1)                                # bit p % 32 of word p / 32
+            counts = bits.sum(1)
+            self.mask_words = words.where(words < 2 ** 31, words - 2 ** 32).to(torch.int32).to(device)   # uint32 bit pattern
+            self.mask_prefix = (torch.cumsum(counts, 0) - counts).to(torch.int32).to(device)
 
     def singulars(self):
         return self._singulars
@@ -80,6 +92,8 @@ class Inpainting(H_functions):
 
     def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
         """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
+        if self.mask_words is not None:
+            return K.ddim_mix_bwd_inpaint_px(xt_in, e, at, at_next, y, self.mask_words, self.mask_prefix, g_e_out=g_e_out)
         return K.ddim_mix_bwd_inpaint(xt_in, e, at, at_next, y, self.slot, g_e_out=g_e_out)
 
 

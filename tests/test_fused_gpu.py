@@ -192,3 +192,31 @@ def test_fused_cs_last_vjp_equals_two_kernel_path(dim, B, ratio):
     gx_a, ge_a = K.ddim_mix_bwd(g, xt, e, at, atn, final_clip=True)
     loss_b, gx_b, ge_b = op.fused_last_vjp(xt, e, at, atn, y, xt_next=cur)
     assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b) and torch.equal(loss_a, loss_b)
+
+
+def test_fused_inpaint_pixel_mask_form_equals_slot_form_and_ragged_masks_fall_back():
+    import nhmc.kernels as K
+    from nhmc import operators
+    dim, B = 64, 3
+    g_ = torch.Generator().manual_seed(5)
+    op = operators.Inpainting(3, dim, oops.random_inpaint_missing(dim, generator=g_), 'cuda')
+    assert op.mask_words is not None                                   # whole-pixel mask -> bit mask + prefix counts
+    xt = (torch.randn(B, 3, dim, dim, generator=g_) * 0.5).cuda()
+    e = torch.randn(B, 6, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    b = osched.betas_fp32()
+    at = osched.alpha_bar(b, torch.full((B,), 250)).cuda()
+    atn = osched.alpha_bar(b, torch.full((B,), -1)).cuda()
+    a = K.ddim_mix_bwd_inpaint(xt, e, at, atn, y, op.slot)
+    p = K.ddim_mix_bwd_inpaint_px(xt, e, at, atn, y, op.mask_words, op.mask_prefix)
+    for u, v in zip(a, p):
+        assert torch.equal(u, v)
+    # a mask that drops single channels is not pixel-aligned: the operator keeps the dense slot map
+    ragged = operators.Inpainting(3, dim, torch.tensor([0, 5, 7, 100, 3 * dim * dim - 1]), 'cuda')
+    assert ragged.mask_words is None
+    y2 = torch.randn(B, ragged.M, generator=g_).cuda()
+    cur = K.ddim_mix_fwd(xt, e, at, atn, final_clip=True)['xt_next']
+    la, g = ragged.data_term(cur, y2, apply_clip=False)
+    gx_a, ge_a = K.ddim_mix_bwd(g, xt, e, at, atn, final_clip=True)
+    lb, gx_b, ge_b = ragged.fused_last_vjp(xt, e, at, atn, y2)
+    assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b)
