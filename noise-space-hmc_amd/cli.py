@@ -112,6 +112,17 @@ def main(argv=None):
     mc.pop('var_type', None)
     model = unet.create_model(**mc).to(device).eval().requires_grad_(False)
     algo = plugin.HMC(model, op, opt.sigma_0)
+    if world > 1:
+        # the first score-network call on a machine fills MIOpen's on-disk kernel cache (~1 min): one rank does it at
+        # the shape the run will use, the others wait instead of racing through the same compiles
+        if rank == 0:
+            n0 = max(1, min(opt.chains, opt.score_chunk or opt.chains))
+            xw = torch.zeros(n0, ch, size, size, device=device, requires_grad=True)
+            with torch.enable_grad():
+                out = model(xw, torch.full((n0,), 500.0, device=device))
+            torch.autograd.grad(out, xw, torch.ones_like(out))
+            torch.cuda.synchronize()
+        sharding.barrier()
     d = config['diffusion']
     b = torch.from_numpy(schedule.get_beta_schedule(d['beta_schedule'], beta_start=d['beta_start'], beta_end=d['beta_end'],
                                                     num_diffusion_timesteps=d['num_diffusion_timesteps'])).float().to(device)
