@@ -318,6 +318,7 @@ def main():
         if in_situ:
             roof['in_situ_us'] = sum(a.elapsed_time(b_) for a, b_ in in_situ) * 1e3 / len(in_situ)
             roof['in_situ_gbs'] = 6 * B * CH * DIM * DIM * 4 / (roof['in_situ_us'] * 1e-6) / 1e9
+            roof['in_situ_frac'] = roof['in_situ_gbs'] / HBM_PEAK_GBS
             roof['in_situ_note'] = ('per-launch event pairs inside the timed steps; there the kernel takes the second gradient '
                                     'pointer (R x,p,g,g2 + W x,p = 6T = 24 B/element), caches cold after the score network')
         traffic = None
