@@ -10,9 +10,10 @@ tau = 1.0, eps = 0.05, timesteps = 3, 64 chains PER GPU (weak scaling: chains ar
 synthetic inputs, guided-diffusion FFHQ U-Net architecture with random-init fp32 weights (the checkpoint
 is fetch-only; random init is also the reference's own fallback).
 
-A "step" is one leapfrog step of every chain of the batch: the decode (3 x [score forward + DDIM mix]),
-the data term, the backward (3 x [DDIM mix VJP + score input-gradient]) and the fused momentum+position
-update -- nothing is skipped or cached.  value = N * 64 * K / (max-over-ranks time).
+A "step" is one leapfrog step of every chain of the batch, exactly as the sampler executes it
+(`LeapfrogEngine.step`): the decode (3 x [score forward + DDIM mix]), the data term, the backward
+(3 x [DDIM mix VJP + score input-gradient]) and the fused momentum+position update -- nothing is skipped or
+cached.  value = N * 64 * K / (max-over-ranks time).
 
 Extra objects on the same line:
   roofline      the dominant HIP kernel (fused leapfrog update, 20 B/element = 5T per chain):
@@ -20,9 +21,17 @@ Extra objects on the same line:
                 over a region of back-to-back launches that rotates over buffer sets larger than the
                 256 MiB Infinity Cache, so every launch streams from HBM as it does between two score
                 evaluations.  `in_situ_us` is the same kernel timed per launch inside the timed steps.
-  hot_path      the HIP-side of one step alone (score replaced by a resident tensor): chain-steps/s
-  cpu_baseline  the oracle (CPU restatement, validated bit-exact against the reference) doing the same
-                step on the host cores: B = 1, one step, same U-Net architecture.
+                `traffic` is the PMC figure of the committed profile named in `traffic_source` (counters need a
+                rocprofv3 pass of their own; they cannot be read inside this run).
+  hot_path_only the HIP side of one step THROUGH THE ENGINE (the score replaced by a resident tensor whose
+                backward hands back a resident gradient): what the sampler launches, minus the U-Net.
+  by_deg        configs[2] / configs[3] operators (sr4, deblur_aniso): hot path, dominant data-term kernel
+                against its roofline (fp32 MFMA for the spectral chain), end-to-end chain-steps/s of a few steps.
+  cpu_baseline  the oracle (CPU restatement, validated bit-exact against the reference) on the host cores:
+                with the U-Net in the loop (B = 1) and score-stubbed at B = 1 and B = 64.
+
+`--latent` prints the line of BASELINE configs[4] instead (hmc_latent: 16 chains per GPU of [3,64,64] latents, LDM
+U-Net + VQ-f4 first stage at the configs/config_ffhq_latent.yml widths, random init, inpaint_random at 256x256).
 """
 import argparse
 import json
@@ -37,8 +46,11 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
 B_PER_GPU, DIM, CH = 64, 256, 3
+B_LATENT, ZDIM = 16, 64          # configs[4]: batch 128 over 8 GPUs
 SIGMA0_CLI, TAU, EPS, TIMESTEPS = 0.05, 1.0, 0.05, 3
+SPECTRAL_FLOP_PER_CHAIN = 805.3e6          # 8 GEMMs x 3 channels x 33.55 MFLOP
 
 
 def parse():
@@ -47,24 +59,27 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--chunk', type=int, default=32, help='chains per score-network call (activation memory)')
-    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='chains per GPU (BASELINE: 64)')
+    ap.add_argument('--batch', type=int, default=None, help='chains per GPU (BASELINE: 64; 16 with --latent)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-by-deg', action='store_true', help='skip the sr4 / deblur_aniso legs')
     ap.add_argument('--kernel-only', action='store_true', help='skip the end-to-end steps (profiling the HIP kernels)')
     ap.add_argument('--roofline-launches', type=int, default=200)
     ap.add_argument('--deg', default='inpaint_random',
                     help='degradation: inpaint_random (the BASELINE metric), sr4 (configs[2]), deblur_aniso (configs[3]), ...')
+    ap.add_argument('--latent', action='store_true', help='BASELINE configs[4]: hmc_latent with the LDM U-Net + VQ-f4 decode in the loop')
     ap.add_argument('--rehearse-shared-gpu', action='store_true',
                     help='rehearsal only: all ranks use cuda:0 over gloo (checks the N>1 control flow on a 1-GPU box)')
     return ap.parse_args()
 
 
-def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random'):
+def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=None):
     import nhmc.kernels as K
-    from nhmc import operators, plugin, sampler, schedule, unet
+    from nhmc import operators, plugin, schedule, unet
     gen = torch.Generator().manual_seed(seed)
     op = operators.build_operator(deg, CH, DIM, device, generator=gen)
-    torch.manual_seed(seed)
-    model = unet.create_model(**unet.FFHQ_CONFIG).to(device).eval().requires_grad_(False)
+    if model is None:
+        torch.manual_seed(seed)
+        model = unet.create_model(**unet.FFHQ_CONFIG).to(device).eval().requires_grad_(False)
     algo = plugin.HMC(model, op, 2 * SIGMA0_CLI)
     b = torch.from_numpy(schedule.get_beta_schedule('linear', beta_start=1e-4, beta_end=0.02,
                                                     num_diffusion_timesteps=1000)).float().to(device)
@@ -78,14 +93,14 @@ def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random'):
     return dict(op=op, algo=algo, b=b, seq=seq, seq_next=seq_next, x=x, p=p, y=y, model=model)
 
 
-def leapfrog_roofline(device, B, launches):
+def leapfrog_roofline(device, B, launches, n_elem=CH * DIM * DIM):
     """Dominant kernel: nhmc_leapfrog_fused(MID).  Rotates over R buffer sets (x,p,g) whose total
     footprint exceeds the Infinity Cache, events around the whole region on the launch stream."""
     import nhmc.kernels as K
-    N = CH * DIM * DIM
+    N = n_elem
     per_set = 3 * B * N * 4
     R = max(2, math.ceil(3 * (256 << 20) / per_set))                 # >= 3x the 256 MiB Infinity Cache
-    sets = [tuple(K.randn_philox((B, CH, DIM, DIM), 1, 0, 3 * r + k, device=device) for k in range(3)) for r in range(R)]
+    sets = [tuple(K.randn_philox((B, N), 1, 0, 3 * r + k, device=device) for k in range(3)) for r in range(R)]
     eps = torch.full((B,), 1e-3, dtype=torch.float64, device=device)
     sig = torch.full((B,), 1.7, dtype=torch.float64, device=device)
     for r in range(R):                                               # warm-up (code object load, TLB)
@@ -114,52 +129,91 @@ def leapfrog_roofline(device, B, launches):
     del sets, flat
     torch.cuda.empty_cache()
     return dict(kernel='k_leapfrog<MID> (nhmc_leapfrog_fused)', avg_us=avg_s * 1e6, bytes_per_launch=alg_bytes,
-                achieved=alg_bytes / avg_s / 1e9, launches=launches, buffer_sets=R,
+                achieved=alg_bytes / avg_s / 1e9, launches=launches, chains_per_launch=B, buffer_sets=R,
                 footprint_mib=R * per_set / 2 ** 20, copy_kernel_gbs=copy_gbs,
                 frac_of_copy_kernel=alg_bytes / avg_s / 1e9 / copy_gbs,
                 copy_note='nhmc_copy_probe: 1 read : 1 write streaming copy, same buffers; the update is 3 reads : 2 writes')
 
 
-def hot_path_only(device, prob, B, steps):
-    """The HIP side of one leapfrog step with the score output held resident (kernel-comparable number)."""
+class _ResidentScore(torch.autograd.Function):
+    """Score stand-in for the hot-path leg: forward hands out a resident [B,2C,H,W] tensor, backward a resident
+    input-gradient -- no arithmetic, so what is timed is exactly what the engine launches around the U-Net."""
+
+    @staticmethod
+    def forward(ctx, x, e, gs):
+        ctx.gs = gs
+        return e.view_as(e)
+
+    @staticmethod
+    def backward(ctx, g_e):
+        return ctx.gs, None, None
+
+
+def hot_path_only(device, prob, B, steps, chunk=None):
+    """The HIP side of one leapfrog step through LeapfrogEngine.step (kernel-comparable number)."""
     import nhmc.kernels as K
-    op = prob['op']
-    x, p, y = prob['x'].clone(), prob['p'].clone(), prob['y']
+    from nhmc import sampler
     e = K.randn_philox((B, 2 * CH, DIM, DIM), 7, 0, 0, device=device)
     gs = K.randn_philox((B, CH, DIM, DIM), 7, 0, 1, scale=1e-3, device=device)
-    ge = [torch.zeros_like(e) for _ in range(3)]            # persistent score-gradient buffers (sigma-channels stay zero)
-    at =[torch.tensor([a], device=device).expand(B).contiguous() for a in (0.0033001585, 0.0777966604, 0.5214230418)]
-    atn = [torch.tensor([a], device=device).expand(B).contiguous() for a in (0.0777966604, 0.5214230418, 1.0)]
+
+    def score(x, t):
+        n = x.shape[0]
+        return _ResidentScore.apply(x, e[:n], gs[:n])
+
+    eng = sampler.LeapfrogEngine(score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device, chunk=chunk)
+    x, p, y = prob['x'].clone(), prob['p'].clone(), prob['y']
     eps = torch.full((B,), EPS, dtype=torch.float64, device=device)
     sig = torch.full((B,), 1.7, dtype=torch.float64, device=device)
-
-    def step():
-        cur, ins = x, []
-        for s in range(3):
-            ins.append(cur)
-            cur = K.ddim_mix_fwd(cur, e, at[s], atn[s], final_clip=(s == 2))['xt_next']
-        g2 = None
-        for s in (2, 1, 0):
-            if s == 2 and hasattr(op, 'fused_last_vjp'):            # data term fused into the last-step VJP
-                extra = dict(xt_next=cur) if getattr(op, 'fused_wants_decode', False) else {}
-                loss, g, g_e = op.fused_last_vjp(ins[s], e, at[s], atn[s], y, g_e_out=ge[s], **extra)
-            elif s == 2:
-                loss, g = op.data_term(cur, y, apply_clip=False)
-                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], final_clip=True, g_e_out=ge[s])
-            else:
-                g, g_e = K.ddim_mix_bwd(g, ins[s], e, at[s], atn[s], gout2=g2, g_e_out=ge[s])
-            g2 = gs                                                 # stands in for the score's input-gradient
-        K.leapfrog_fused(K.LF_MID, x, p, g, eps, sig, 1.0, g2=g2)
+    ws = K.leapfrog_ws(B, x[0].numel(), device)
     for _ in range(3):
-        step()
+        eng.step(K.LF_MID, x, x, p, y, eps, sig, 1.0, ws)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        eng.step(K.LF_MID, x, x, p, y, eps, sig, 1.0, ws)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return dict(value=B * steps / dt, unit='chain-steps/s', ms_per_step=1e3 * dt / steps, steps=steps,
-                note='score output resident (no U-Net); 3 mix fwd + (data term + last VJP fused) + 2 mix VJP + fused update')
+                note='LeapfrogEngine.step with a resident score (no U-Net): 3 mix fwd + (data term + last VJP fused) + 2 mix VJP '
+                     '+ fused update, as the sampler launches them')
+
+
+def data_term_roofline(device, prob, B, launches=30):
+    """Dominant data-term kernel of a non-inpaint operator: the fused (data term + last VJP) call, timed with events.
+    deblur_aniso: 8 fp32-MFMA products, 805.3 MFLOP per chain against the fp32 matrix peak; sr4: 4T + y against HBM."""
+    import nhmc.kernels as K
+    op = prob['op']
+    e = K.randn_philox((B, 2 * CH, DIM, DIM), 9, 0, 0, device=device)
+    ge = torch.zeros_like(e)
+    at = torch.full((B,), 0.5214230418, device=device)
+    atn = torch.ones(B, device=device)
+    x, y = prob['x'], prob['y']
+    xt_next = K.ddim_mix_fwd(x, e, at, atn, final_clip=True)['xt_next']
+    extra = dict(xt_next=xt_next) if getattr(op, 'fused_wants_decode', False) else {}
+
+    def call():
+        return op.fused_last_vjp(x, e, at, atn, y, g_e_out=ge, **extra)
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
+    if hasattr(op, 'factors'):
+        flops = SPECTRAL_FLOP_PER_CHAIN * B
+        return dict(bound='mfma', achieved=round(flops / avg_s / 1e12, 1), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                    frac=round(flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, avg_us=round(avg_s * 1e6, 1),
+                    kernel='spectral chain: data term + last-step VJP (nhmc_data_spectral_vjp), fp32 MFMA',
+                    flops_per_call=flops, dtype='f32')
+    T = CH * DIM * DIM * 4
+    alg = (4 * T + op.M * 4) * B
+    return dict(bound='hbm', achieved=round(alg / avg_s / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None, avg_us=round(avg_s * 1e6, 1),
+                kernel='data term fused with the last-step VJP (R xt, e; W g_xt, g_e; R y)', bytes_per_call=alg)
 
 
 def host_cores():
@@ -176,7 +230,9 @@ def host_cores():
 
 
 def cpu_baseline(seed=5678):
-    """Oracle leapfrog step on the host cores: B = 1, same architecture, one step (~10-30 s)."""
+    """Oracle leapfrog steps on the host cores: (i) with the FFHQ U-Net in the loop at B = 1 -- `value`,
+    the number comparable with the headline metric; (ii) score-stubbed at B = 1 and B = 64 -- comparable with
+    `hot_path_only` and the HIP kernels."""
     from oracle import hmc_ref, operators as oops, schedule as osched
     from nhmc import unet
     torch.set_num_threads(host_cores())
@@ -187,18 +243,32 @@ def cpu_baseline(seed=5678):
     net = unet.create_model(**unet.FFHQ_CONFIG).eval().requires_grad_(False)
     b = osched.betas_fp32()
     seq, seq_next = osched.timestep_ladder(1000, TIMESTEPS)
-    x = torch.randn(1, CH, DIM, DIM, generator=gen)
-    p = torch.randn(1, CH, DIM, DIM, generator=gen)
-    y = op.H(torch.rand(1, CH, DIM, DIM, generator=gen) * 2 - 1) + 0.1 * torch.randn(1, op.M, generator=gen)
+
+    def run(model, B, steps):
+        x = torch.randn(B, CH, DIM, DIM, generator=gen)
+        p = torch.randn(B, CH, DIM, DIM, generator=gen)
+        y = op.H(torch.rand(B, CH, DIM, DIM, generator=gen) * 2 - 1) + 0.1 * torch.randn(B, op.M, generator=gen)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            xl = x.clone().requires_grad_(True)
+            _, _, _, g = hmc_ref._data_loss_and_grad(xl, b, seq, seq_next, model, op, y)      # decode + gradient
+            x, p = hmc_ref.leapfrog_update('mid', x, p, g, eps=EPS, sigma_y=1.7, m=1.0)[:2]   # momentum + position
+        return time.perf_counter() - t0
+
+    def stub(x, t):                        # two elementwise ops standing in for the score (differentiable)
+        return torch.cat([0.5 * x, 0.25 * x], dim=1)
+
     steps = 4                                                                       # ~15-20 s on the box's 16-CPU quota
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        xl = x.clone().requires_grad_(True)
-        _, _, _, g = hmc_ref._data_loss_and_grad(xl, b, seq, seq_next, net, op, y)  # decode + gradient
-        x, p = hmc_ref.leapfrog_update('mid', x, p, g, eps=EPS, sigma_y=1.7, m=1.0)[:2]   # momentum + position
-    dt = time.perf_counter() - t0
+    dt = run(net, 1, steps)
+    run(stub, 1, 2)
+    s1, n1 = run(stub, 1, 20), 20
+    s64, n64 = run(stub, 64, 3), 3
     return dict(value=steps / dt, unit='chain-steps/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle (oracle/hmc_ref.py) leapfrog steps, B=1, {steps} consecutive steps, FFHQ U-Net fp32 on CPU: {dt:.1f} s')
+                sample=f'oracle (oracle/hmc_ref.py) leapfrog steps, B=1, {steps} consecutive steps, FFHQ U-Net fp32 on CPU: {dt:.1f} s',
+                score_stubbed=dict(b1_chain_steps_per_s=round(n1 / s1, 1), b1_ms_per_step=round(1e3 * s1 / n1, 2),
+                                   b64_chain_steps_per_s=round(64 * n64 / s64, 1), b64_ms_per_step=round(1e3 * s64 / n64, 1),
+                                   sample=f'same oracle step with a two-op stand-in score: {n1} steps at B=1 ({s1:.1f} s), '
+                                          f'{n64} steps at B=64 ({s64:.1f} s); compare with hot_path_only'))
 
 
 def single_chain_rate(eng, x, p, y, eps, sig, with_graph):
@@ -208,42 +278,156 @@ def single_chain_rate(eng, x, p, y, eps, sig, with_graph):
     import nhmc.kernels as K
     x1, p1, y1 = x[:1].clone(), p[:1].clone(), y[:1].contiguous()
     e1, s1 = eps[:1].contiguous(), sig[:1].contiguous()
-    for _ in range(2):
-        _, _, ga, gb = eng.decode_and_grad(x1, y1)
-        K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        _, _, ga, gb = eng.decode_and_grad(x1, y1)
-        K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
-    torch.cuda.synchronize()
-    eager = 5 / (time.perf_counter() - t0)
-    graphed = None
-    try:                                                 # same step replayed as one hipGraph per decode+gradient
-        if not with_graph:
-            raise RuntimeError('not measured at N > 1')
+    ws = K.leapfrog_ws(1, x1[0].numel(), x1.device)
+
+    def rate(graph):
         for _ in range(2):
-            _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
-            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+            eng.step(K.LF_MID, x1, x1, p1, y1, e1, s1, 1.0, ws, graph=graph)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
-            _, _, ga, gb = eng.decode_and_grad(x1, y1, graph=True)
-            K.leapfrog_fused(K.LF_MID, x1, p1, ga, e1, s1, 1.0, g2=gb)
+            eng.step(K.LF_MID, x1, x1, p1, y1, e1, s1, 1.0, ws, graph=graph)
         torch.cuda.synchronize()
-        graphed = round(5 / (time.perf_counter() - t0), 2)
+        return 5 / (time.perf_counter() - t0)
+    eager = rate(False)
+    try:                                                 # same step replayed as one hipGraph per decode+gradient
+        if not with_graph:
+            raise RuntimeError('not measured at N > 1')
+        graphed = round(rate(True), 2)
     except RuntimeError as exc:                          # capture support is the framework's, not ours: report, go on
         graphed = f'capture failed: {str(exc)[:80]}'
-    single = dict(value=round(eager, 2), value_hipgraph=graphed, unit='leapfrog steps/s', chains=1,
-                  reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
-    return single
+    return dict(value=round(eager, 2), value_hipgraph=graphed, unit='leapfrog steps/s', chains=1,
+                reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
+
+
+def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding, device):
+    """The contract's timed region: W untimed steps, barrier + synchronize, K steps, synchronize + barrier, max over ranks."""
+    import nhmc.kernels as K
+
+    def step():
+        return eng.step(K.LF_MID, x, x, p, y, eps, sig, 1.0, ws)
+    if world > 1:
+        # the first score-network call on a machine fills MIOpen's on-disk kernel cache (~1 min); let one rank do it
+        # instead of N ranks racing through the same compiles and the same cache files
+        if rank == 0:
+            step()
+            torch.cuda.synchronize()
+        sharding.barrier()
+    for _ in range(warmup):
+        step()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    eng.update_events = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, loss = step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, device)
+    events, eng.update_events = eng.update_events, None
+    return dt, loss.clone(), events
+
+
+def degradation_leg(device, deg, model, B, chunk, steps=2):
+    """configs[2] / configs[3]: the same step with another operator -- hot path, data-term roofline, a few end-to-end steps."""
+    import nhmc.kernels as K
+    from nhmc import sampler, sharding
+    prob = build_problem(device, B, 0, deg=deg, model=model)
+    eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device, chunk=chunk)
+    eps = torch.full((B,), EPS, dtype=torch.float64, device=device)
+    sig = torch.full((B,), 2 * SIGMA0_CLI + 1.6, dtype=torch.float64, device=device)
+    ws = K.leapfrog_ws(B, CH * DIM * DIM, device)
+    dt, _, _ = timed_steps(eng, prob['x'], prob['p'], prob['y'], eps, sig, ws, 1, steps, 1, 0, sharding, device)
+    hot = hot_path_only(device, prob, B, 20, chunk=chunk)
+    return dict(value=round(B * steps / dt, 3), unit='chain-steps/s', steps=steps, ms_per_step=round(1e3 * dt / steps, 2),
+                hot_path_only=dict(value=round(hot['value'], 1), ms_per_step=round(hot['ms_per_step'], 4)),
+                roofline=data_term_roofline(device, prob, B), M=int(prob['op'].M))
+
+
+def latent_main(args):
+    """BASELINE configs[4]: one leapfrog step of hmc_latent = 3 x [LDM U-Net forward (no gradient: ddpm.py:892) + DDIM
+    mix] + final clip + VQ codebook lookup + VQ-f4 decoder forward + inpainting data term at 256x256 + decoder backward
+    + straight-through + 3 mix VJPs + fused update, 16 chains per GPU."""
+    import nhmc.kernels as K
+    from nhmc import ldm, operators, plugin, sampler, sharding
+    rank, local_rank, world = sharding.init_process_group('gloo' if args.rehearse_shared_gpu else None)
+    local_rank = 0 if args.rehearse_shared_gpu else local_rank
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    B = args.batch or B_LATENT
+    seed = 5678
+    torch.manual_seed(seed)
+    model = ldm.create_latent_model(ckpt=None, quiet=True).to(device)
+    op = operators.build_operator('inpaint_random', CH, DIM, device, generator=torch.Generator().manual_seed(seed))
+    algo = plugin.HMCLatent(model, op, 2 * SIGMA0_CLI)
+    table = torch.cat([model.alphas_cumprod_prev[0:1], model.alphas_cumprod])
+    seq, seq_next = [250, 500, 750], [-1, 250, 500]
+    eng = sampler.LeapfrogEngine(algo.score, op, None, seq, seq_next, device, chunk=args.chunk, alpha_table=table,
+                                 image_map=model.differentiable_decode_first_stage)
+    lo = rank * B
+    zshape = (B, model.channels, ZDIM, ZDIM)
+    x = K.randn_philox(zshape, seed, lo, 0, device=device)
+    p = K.randn_philox(zshape, seed, lo, 1, device=device)
+    x_true = K.randn_philox((B, CH, DIM, DIM), seed, lo, 2, device=device).clamp_(-1, 1)
+    y = op.H(x_true) + (2 * SIGMA0_CLI) * torch.randn(B, op.M, device=device,
+                                                       generator=torch.Generator(device=device).manual_seed(seed + lo))
+    eps = torch.full((B,), 0.1, dtype=torch.float64, device=device)            # main_sampling_latent.py:828-830 default
+    sig = torch.full((B,), 0.5, dtype=torch.float64, device=device)            # --sigma_y default, :832
+    ws = K.leapfrog_ws(B, x[0].numel(), device)
+    dt, loss, _ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
+    stats = torch.stack([loss.float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
+    allstats = sharding.gather_chains(stats.cpu() if args.rehearse_shared_gpu else stats, world * B, rank, world)
+    if rank == 0:
+        roof = leapfrog_roofline(device, B_PER_GPU, args.roofline_launches)
+        # the HIP kernel this path adds: codebook lookup of all 16 x 4096 latent pixels against 8192 codes
+        z = K.randn_philox(zshape, 3, 0, 0, device=device).clamp_(-1, 1)
+        cb = model.first_stage_model.quantize.embedding.weight.detach().contiguous()
+        for _ in range(3):
+            K.vq_nearest(z, cb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            K.vq_nearest(z, cb)
+        e1.record()
+        torch.cuda.synchronize()
+        vq_us = e0.elapsed_time(e1) * 1e3 / 50
+        n_pairs = B * ZDIM * ZDIM * cb.shape[0]
+        line = {
+            'metric': 'HMC leapfrog chain-steps/sec (FFHQ-latent 64x64x3 hmc_latent, inpaint_random at 256x256, LDM U-Net + VQ-f4 decode in the loop)',
+            'value': round(world * B * args.steps / dt, 3), 'unit': 'chain-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[4]: FFHQ-latent [{model.channels},64,64] (the reference config has 3 latent '
+                                   f'channels; BASELINE.json says 4), hmc_latent, inpaint_random sigma_0=0.05 eps=0.1 sigma_y=0.5 '
+                                   f'timesteps=3, {B} chains per GPU, LDM U-Net (224 ch) + VQ-f4 decoder (128 ch, 8192 codes) random-init fp32',
+                       'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
+                       'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
+            'roofline': dict(bound='hbm', achieved=round(roof['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                             frac=round(roof['achieved'] / HBM_PEAK_GBS, 4), traffic=None, kernel=roof['kernel'],
+                             avg_us=round(roof['avg_us'], 2),
+                             note='the fused update at the pixel path\'s 64 x 196 608 elements (the latent state is 16 x 12 288: launch-bound)'),
+            'vq_kernel': dict(kernel='k_vq_nearest<3> (nhmc_vq_nearest)', avg_us=round(vq_us, 1), pairs=n_pairs,
+                              gpairs_per_s=round(n_pairs / vq_us / 1e3, 1),
+                              note='one thread per latent pixel, codebook staged through LDS; torch would materialise a '
+                                   f'{n_pairs * 4 / 2 ** 30:.1f} GiB distance matrix'),
+            'final_gather': dict(chains=int(allstats.shape[0]), loss_mean=float(allstats[:, 0].double().mean())),
+            'cpu_baseline': None,
+        }
+        print(json.dumps(line), flush=True)
+    sharding.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 def main():
     args = parse()
+    assert torch.cuda.is_available(), 'bench.py needs a GPU; the HIP path has no CPU fallback'
+    if args.latent:
+        return latent_main(args)
     import nhmc.kernels as K
     from nhmc import sampler, sharding
-    assert torch.cuda.is_available(), 'bench.py needs a GPU; the HIP path has no CPU fallback'
     if args.rehearse_shared_gpu:
         rank, local_rank, world = sharding.init_process_group('gloo')
         local_rank = 0
@@ -253,82 +437,58 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    B = args.batch
+    B = args.batch or B_PER_GPU
     lo = rank * B                                                      # global chain ids of this rank (weak scaling)
     prob = build_problem(device, B, lo, deg=args.deg)
     eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device,
                                  chunk=args.chunk)
     x, p, y = prob['x'], prob['p'], prob['y']
+    N = x[0].numel()
     eps = torch.full((B,), EPS, dtype=torch.float64, device=device)
     sig = torch.full((B,), 2 * SIGMA0_CLI + 1.6, dtype=torch.float64, device=device)     # sigma_y at epoch 0
+    ws = K.leapfrog_ws(B, N, device)
+
+    ms_per_step = value = gather = None
     in_situ = []
-    last = {}
-
-    def step(timed):
-        xt, loss, ga, gb = eng.decode_and_grad(x, y)
-        last['loss'] = loss
-        if timed:
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-        K.leapfrog_fused(K.LF_MID, x, p, ga, eps, sig, 1.0, g2=gb)
-        if timed:
-            b_.record()
-            in_situ.append((a, b_))
-
-    ms_per_step = value = None
     if not args.kernel_only:
-        if world > 1:
-            # the first score-network call on a machine fills MIOpen's on-disk kernel cache (~1 min); let one rank do it
-            # instead of N ranks racing through the same compiles and the same cache files
-            if rank == 0:
-                step(False)
-                torch.cuda.synchronize()
-            sharding.barrier()
-        for _ in range(args.warmup):
-            step(False)
-        sharding.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(True)
-        torch.cuda.synchronize()
-        sharding.barrier()
-        dt = sharding.max_over_ranks(time.perf_counter() - t0, device)
+        dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
         ms_per_step = 1e3 * dt / args.steps
         value = world * B * args.steps / dt
-
-    # the one collective of the design: per-chain results gathered once, after the timed region (RCCL over xGMI at N > 1)
-    gather = None
-    if not args.kernel_only:
-        stats = torch.stack([last['loss'].float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
+        # the one collective of the design: per-chain results gathered once, after the timed region (RCCL over xGMI at N > 1)
+        stats = torch.stack([loss.float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
         torch.cuda.synchronize()
         sharding.barrier()
         t0 = time.perf_counter()                                   # times the collective alone
-        if args.rehearse_shared_gpu:
-            allstats = sharding.gather_chains(stats.cpu(), world * B, rank, world)
-        else:
-            allstats = sharding.gather_chains(stats, world * B, rank, world)
+        allstats = sharding.gather_chains(stats.cpu() if args.rehearse_shared_gpu else stats, world * B, rank, world)
         torch.cuda.synchronize()
         gather = dict(chains=int(allstats.shape[0]), ms=round(1e3 * (time.perf_counter() - t0), 3),
                       loss_mean=float(allstats[:, 0].double().mean()))
-    roof = hot = cpu = single = None
+    roof = hot = cpu = single = by_deg = None
     if rank == 0:
         roof = leapfrog_roofline(device, B, args.roofline_launches)
-        hot = hot_path_only(device, prob, B, 20)
+        hot = hot_path_only(device, prob, B, 20, chunk=args.chunk)
         if in_situ:
-            roof['in_situ_us'] = sum(a.elapsed_time(b_) for a, b_ in in_situ) * 1e3 / len(in_situ)
-            roof['in_situ_gbs'] = 6 * B * CH * DIM * DIM * 4 / (roof['in_situ_us'] * 1e-6) / 1e9
+            us = [a.elapsed_time(b_) * 1e3 for a, b_, _ in in_situ]
+            chains = sum(n for _, _, n in in_situ) / len(in_situ)
+            roof['in_situ_us'] = sum(us) / len(us)
+            roof['in_situ_chains_per_launch'] = chains
+            roof['in_situ_gbs'] = 6 * chains * N * 4 / (roof['in_situ_us'] * 1e-6) / 1e9
             roof['in_situ_frac'] = roof['in_situ_gbs'] / HBM_PEAK_GBS
-            roof['in_situ_note'] = ('per-launch event pairs inside the timed steps; there the kernel takes the second gradient '
-                                    'pointer (R x,p,g,g2 + W x,p = 6T = 24 B/element), caches cold after the score network')
-        traffic = None
+            roof['in_situ_note'] = ('per-launch event pairs inside the timed steps: one launch per score chunk, with the second '
+                                    'gradient pointer (R x,p,g,g2 + W x,p = 6T = 24 B/element), caches cold after the score network')
+        traffic = source = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_leapfrog.json')
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
+                rec = json.load(f)
+            traffic, source = rec.get('hbm_bytes_per_launch'), rec.get('source', 'profiles/traffic_leapfrog.json')
         roofline = dict(bound='hbm', achieved=round(roof['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(roof['achieved'] / HBM_PEAK_GBS, 4), traffic=traffic,
+                        frac=round(roof['achieved'] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=source,
                         **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in roof.items() if k != 'achieved'})
+        if world == 1 and not args.kernel_only and not args.no_by_deg and args.deg == 'inpaint_random':
+            by_deg = {}
+            for deg in ('sr4', 'deblur_aniso'):
+                by_deg[deg] = degradation_leg(device, deg, prob['model'], B, args.chunk)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
         if not args.kernel_only:
@@ -344,7 +504,8 @@ def main():
                                    f'timesteps=3, {B} chains per GPU, FFHQ U-Net architecture random-init fp32',
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
-            'roofline': roofline, 'hot_path_only': hot, 'single_chain': single, 'final_gather': gather, 'cpu_baseline': cpu,
+            'roofline': roofline, 'hot_path_only': hot, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
+            'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     sharding.barrier()

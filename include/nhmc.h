@@ -71,6 +71,13 @@ int nhmc_leapfrog_fused(int mode, float* x, float* p, const float* g, const floa
                         const double* eps, const double* sigma_y, double m_inv,
                         int n_chains, int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
 
+/* NHMC_LF_FIRST out of place in x: reads x_in, writes the proposal to x_out (x_in != x_out) and updates p in place.
+ * The caller's accepted position survives the trajectory, so a reject needs no saved copy (main_sampling.py:699
+ * clones x for that).  Same traffic as the in-place form. */
+int nhmc_leapfrog_first(const float* x_in, float* x_out, float* p, const float* g, const float* g2,
+                        const double* eps, const double* sigma_y, double m_inv,
+                        int n_chains, int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * a9-a10  DDIM mix, forward               algos/unconditional.py:17-28, main_sampling.py:709
  *   u = (xt - e*sqrt(1-at)) / sqrt(at);  x0 = clip(u,-1,1);  add = sqrt(1-at_next)*e;
@@ -95,6 +102,8 @@ int nhmc_ddim_map_back(const float* x0_t, const float* add_up, const float* at_n
  *   g_e[:, :C] = sqrt(1-at_next)*gin + (-g_xt)*sqrt(1-at);   g_e[:, C:] = 0
  * g_e has e_channels channels (what the score network's backward consumes).  fill_sigma = 1 writes the zero
  * sigma-channels; fill_sigma = 0 leaves channels [C, e_channels) untouched (caller keeps a pre-zeroed buffer: -T).
+ * g_e may be NULL: the score-path gradient is then not formed (a score evaluated without gradient, as the latent
+ * model's apply_model is: ldm/models/diffusion/ddpm.py:892), -T of writes.
  * g_x0 (nullable; then gout2 == NULL and final_clip == 0): split form for the plugin surface,
  * where cal_x0 and map_back are differentiated separately -- gout is then d/d add_up and g_x0
  * replaces gin*sqrt(at_next) as the gradient reaching x0_t.
@@ -327,6 +336,16 @@ int nhmc_mass_from_variance(const float* m2, int L, const int32_t* flags, float*
 int nhmc_schedule_begin_mass(const int32_t* epoch, double* tau, double* eps, double* sigma_y, double* eps_eff,
                              int32_t* active, int32_t* welford_on, const double* sigma_table, int burn, int epochs,
                              int sampling, int n_chains, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * f.1  Codebook lookup of the VQ first stage on decode (latent variant)
+ *      ldm/models/autoencoder.py:274-279 -> taming VectorQuantizer2.forward (not vendored; taming-transformers==0.0.1)
+ *   per latent pixel: k* = argmin_k (|z|^2 + |e_k|^2) - 2 z.e_k (first minimum), z_q = z + (e_k* - z)
+ * z, z_q: [n_chains][channels][hw] (channels = embed_dim in {3, 4}); codebook: [n_embed][channels];
+ * idx (nullable): int32 [n_chains][hw].  The backward of this step is the identity (straight-through).
+ * ---------------------------------------------------------------------------------- */
+int nhmc_vq_nearest(const float* z, const float* codebook, float* z_q, int32_t* idx, int n_chains,
+                    int channels, int64_t hw, int n_embed, nhmc_stream_t stream);
 
 /* PSNR of clamp((xt+1)/2,0,1) against clamp((x_orig+1)/2,0,1)   main_sampling.py:738-739
  * ws: double[n_chains][nhmc_data_tiles(n_elem)]. */

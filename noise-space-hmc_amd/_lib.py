@@ -19,6 +19,7 @@ SIGNATURES = {
     'nhmc_leapfrog_tiles': (I, [I64]),
     'nhmc_leapfrog_ws_bytes': (SZ, [I, I64]),
     'nhmc_leapfrog_fused': (I, [I, P, P, P, P, P, P, D, I, I64, P, P]),
+    'nhmc_leapfrog_first': (I, [P, P, P, P, P, P, P, D, I, I64, P, P]),
     'nhmc_ddim_mix_fwd': (I, [P, P, I, P, P, I, P, P, P, I, I, I64, P]),
     'nhmc_ddim_map_back': (I, [P, P, P, P, I, I64, P]),
     'nhmc_ddim_mix_bwd': (I, [P, P, P, P, P, I, P, P, I, P, P, I, I, I, I64, P]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     'nhmc_mass_sort_ws_bytes': (SZ, [I, I64]),
     'nhmc_mass_from_variance': (I, [P, I, P, P, P, P, SZ, I, I64, P]),
     'nhmc_schedule_begin_mass': (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    'nhmc_vq_nearest': (I, [P, P, P, P, I, I, I64, I, P]),
     'nhmc_psnr': (I, [P, P, P, P, I, I64, P]),
     'nhmc_randn_philox': (I, [P, U64, U32, U32, F, I, I64, P]),
     'nhmc_copy_probe': (I, [P, P, I64, P]),

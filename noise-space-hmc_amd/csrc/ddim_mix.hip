@@ -127,11 +127,11 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd(
       gee[c] = k.c4 * gin + (-gu) * k.c1;
     }
     nhmc_stnt(&g_xt[base + q], ox);
-    nhmc_stnt(&g_e[ebase + q], oe);
+    if (g_e) nhmc_stnt(&g_e[ebase + q], oe);                 // g_e == nullptr: the score carries no gradient
   }
   // learned-sigma channels of the score gradient are zero (the forward slices them away); a caller that keeps a
   // persistent, pre-zeroed g_e buffer passes fill_sigma = 0 and saves this T of writes
-  const int64_t extra = fill_sigma ? e_stride4 - n4 : 0;
+  const int64_t extra = (fill_sigma && g_e) ? e_stride4 - n4 : 0;
   if (extra > 0) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -361,7 +361,7 @@ extern "C" int nhmc_ddim_mix_bwd(const float* gout, const float* gout2, const fl
                                  const float* e, int e_channels, const float* at, const float* at_next, int final_clip,
                                  float* g_xt, float* g_e, int fill_sigma, int n_chains, int channels, int64_t hw,
                                  nhmc_stream_t stream) {
-  if (!gout || !xt || !e || !at || !at_next || !g_xt || !g_e) return NHMC_ERR_ARG;
+  if (!gout || !xt || !e || !at || !at_next || !g_xt) return NHMC_ERR_ARG;      // g_e may be NULL (not wanted)
   if (bad_shape(n_chains, channels, hw, e_channels)) return NHMC_ERR_SHAPE;
   const int64_t n_elem = (int64_t)channels * hw;
   if (g_x0 && (gout2 || final_clip)) return NHMC_ERR_ARG;

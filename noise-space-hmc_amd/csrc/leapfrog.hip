@@ -11,9 +11,11 @@
 
 namespace {
 
-template <int MODE, bool HAS_G2, int VPT>
+// OOP (FIRST only): the position is read from xin and the proposal written to x, so the caller's accepted position
+// survives the trajectory without a copy (same traffic as in place: R xin, W x).
+template <int MODE, bool HAS_G2, int VPT, bool OOP = false>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
-    float4* __restrict__ x, float4* __restrict__ p, const float4* __restrict__ g,
+    const float4* __restrict__ xin, float4* __restrict__ x, float4* __restrict__ p, const float4* __restrict__ g,
     const float4* __restrict__ g2, const double* __restrict__ eps, const double* __restrict__ sigma_y,
     double m_inv, int64_t n4, double* __restrict__ sums_ws) {
   const int chain = blockIdx.y;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     ok[i] = q < n4;
     if (ok[i]) {
-      xv[i] = nhmc_ldnt(&x[base + q]);
+      xv[i] = nhmc_ldnt(OOP ? &xin[base + q] : &x[base + q]);
       pv[i] = nhmc_ldnt(&p[base + q]);
       gv[i] = nhmc_ldnt(&g[base + q]);
       if (HAS_G2) {
@@ -100,11 +102,11 @@ int launch(float* x, float* p, const float* g, const float* g2, const double* ep
   const unsigned tiles = MODE == NHMC_LF_MID ? (unsigned)((n4 + NHMC_BLOCK - 1) / NHMC_BLOCK) : (unsigned)nhmc_leapfrog_tiles(n_elem);
   dim3 grid(tiles, (unsigned)n_chains), block(NHMC_BLOCK);
   if (g2)
-    NHMC_LAUNCH((k_leapfrog<MODE, true, VPT>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
-                       (const float4*)g2, eps, sigma_y, m_inv, n4, ws);
+    NHMC_LAUNCH((k_leapfrog<MODE, true, VPT>), grid, block, 0, st, (const float4*)nullptr, (float4*)x, (float4*)p,
+                (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv, n4, ws);
   else
-    NHMC_LAUNCH((k_leapfrog<MODE, false, VPT>), grid, block, 0, st, (float4*)x, (float4*)p, (const float4*)g,
-                       (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws);
+    NHMC_LAUNCH((k_leapfrog<MODE, false, VPT>), grid, block, 0, st, (const float4*)nullptr, (float4*)x, (float4*)p,
+                (const float4*)g, (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws);
   return nhmc_launch_status();
 }
 
@@ -131,6 +133,27 @@ extern "C" int nhmc_leapfrog_fused(int mode, float* x, float* p, const float* g,
     case NHMC_LF_LAST:  return launch<NHMC_LF_LAST>(x, p, g, g2, eps, sigma_y, m_inv, n_chains, n_elem, sums_ws, st);
     default: return NHMC_ERR_ARG;
   }
+}
+
+extern "C" int nhmc_leapfrog_first(const float* x_in, float* x_out, float* p, const float* g, const float* g2,
+                                   const double* eps, const double* sigma_y, double m_inv, int n_chains,
+                                   int64_t n_elem, double* sums_ws, nhmc_stream_t stream) {
+  if (!x_in || !x_out || x_in == x_out || !p || !g || !eps || !sigma_y || !sums_ws || n_chains <= 0 || n_elem <= 0)
+    return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || !nhmc_aligned16(x_in) || !nhmc_aligned16(x_out) || !nhmc_aligned16(p) || !nhmc_aligned16(g) ||
+      (g2 && !nhmc_aligned16(g2)))
+    return NHMC_ERR_ALIGN;
+  const int64_t n4 = n_elem / 4;
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  hipStream_t st = nhmc_s(stream);
+  if (g2)
+    NHMC_LAUNCH((k_leapfrog<NHMC_LF_FIRST, true, NHMC_VEC_PER_THREAD, true>), grid, block, 0, st, (const float4*)x_in,
+                (float4*)x_out, (float4*)p, (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv, n4, sums_ws);
+  else
+    NHMC_LAUNCH((k_leapfrog<NHMC_LF_FIRST, false, NHMC_VEC_PER_THREAD, true>), grid, block, 0, st, (const float4*)x_in,
+                (float4*)x_out, (float4*)p, (const float4*)g, (const float4*)nullptr, eps, sigma_y, m_inv, n4, sums_ws);
+  return nhmc_launch_status();
 }
 
 extern "C" int nhmc_copy_probe(const float* src, float* dst, int64_t n_elem, nhmc_stream_t stream) {

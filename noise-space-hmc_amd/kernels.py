@@ -71,6 +71,24 @@ def leapfrog_fused(mode, x, p, g, eps, sigma_y, m_inv, sums_ws=None, g2=None):
     _lib.check(rc, 'nhmc_leapfrog_fused')
 
 
+def leapfrog_first(x_in, x_out, p, g, eps, sigma_y, m_inv, sums_ws, g2=None):
+    """FIRST mode out of place in x: x_out <- proposal position, x_in untouched, p updated in place."""
+    lib = _lib.load()
+    B, N = _chains_elems(x_in)
+    if x_out.shape != x_in.shape or p.shape != x_in.shape or g.shape != x_in.shape or (g2 is not None and g2.shape != x_in.shape):
+        raise _lib.NhmcError('x_in, x_out, p, g (and g2) must have the same shape')
+    if x_out.data_ptr() == x_in.data_ptr():
+        raise _lib.NhmcError('leapfrog_first is out of place: x_out must not alias x_in')
+    eps, sigma_y = _f64(eps, B, x_in.device), _f64(sigma_y, B, x_in.device)
+    if sums_ws is None or sums_ws.numel() < B * leapfrog_tiles(N) * 2:
+        raise _lib.NhmcError('sums_ws missing or too small')
+    rc = lib.nhmc_leapfrog_first(_p(x_in, torch.float32, 'x_in'), _p(x_out, torch.float32, 'x_out'), _p(p, torch.float32, 'p'),
+                                 _p(g, torch.float32, 'g'), _p(g2, torch.float32, 'g2'), _p(eps, torch.float64, 'eps'),
+                                 _p(sigma_y, torch.float64, 'sigma_y'), float(m_inv), B, N,
+                                 _p(sums_ws, torch.float64, 'sums_ws'), _stream())
+    _lib.check(rc, 'nhmc_leapfrog_first')
+
+
 # ---- a9-a11 ---------------------------------------------------------------------------------
 def _mix_shapes(xt, e):
     B, Cc = xt.shape[0], xt.shape[1]
@@ -89,12 +107,14 @@ def _alpha(a, B, device):
     return a.to(device=device, dtype=torch.float32).contiguous()
 
 
-def ddim_mix_fwd(xt, e, at, at_next, final_clip=False, want=('xt_next',)):
-    """Returns a dict with the requested outputs among 'xt_next', 'x0_t', 'add_up'."""
+def ddim_mix_fwd(xt, e, at, at_next, final_clip=False, want=('xt_next',), out=None):
+    """Returns a dict with the requested outputs among 'xt_next', 'x0_t', 'add_up'.  out: tensor to write xt_next into."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
-    out = {k: torch.empty_like(xt) for k in want}
+    if out is not None and (out.shape != xt.shape or 'xt_next' not in want):
+        raise _lib.NhmcError('ddim_mix_fwd: out must have the shape of xt and xt_next must be wanted')
+    out = {k: (out if (k == 'xt_next' and out is not None) else torch.empty_like(xt)) for k in want}
     rc = lib.nhmc_ddim_mix_fwd(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                int(final_clip), _p(out.get('xt_next')), _p(out.get('x0_t')), _p(out.get('add_up')),
                                B, Cc, hw, _stream())
@@ -113,15 +133,16 @@ def ddim_map_back(x0_t, add_up, at_next):
     return out
 
 
-def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=None, g_e_out=None):
+def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=None, g_e_out=None, want_g_e=True):
     """-> (g_xt [B,C,H,W], g_e [B,e_channels,H,W]).  g_x0: split form (gout is then d/d add_up).
-    g_e_out: a persistent buffer whose sigma-channels are already zero (they are then not rewritten)."""
+    g_e_out: a persistent buffer whose sigma-channels are already zero (they are then not rewritten).
+    want_g_e=False: the score carries no gradient; g_e is not formed (returned as None)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     g_xt = torch.empty_like(xt)
-    g_e = g_e_out if g_e_out is not None else torch.empty_like(e)
-    if g_e.shape != e.shape:
+    g_e = None if not want_g_e else (g_e_out if g_e_out is not None else torch.empty_like(e))
+    if g_e is not None and g_e.shape != e.shape:
         raise _lib.NhmcError('g_e_out must have the shape of the score output')
     rc = lib.nhmc_ddim_mix_bwd(_p(gout, torch.float32, 'gout'), _p(gout2, torch.float32, 'gout2'),
                                _p(g_x0, torch.float32, 'g_x0'), _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
@@ -130,7 +151,7 @@ def ddim_mix_bwd(gout, xt, e, at, at_next, final_clip=False, gout2=None, g_x0=No
     return g_xt, g_e
 
 
-def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot, g_e_out=None):
+def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot, g_e_out=None, loss_out=None):
     """Last-step VJP fused with the inpainting data term -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
@@ -143,10 +164,10 @@ def ddim_mix_bwd_inpaint(xt, e, at, at_next, y, slot, g_e_out=None):
                                        _p(y, torch.float32, 'y'), _p(slot, torch.int32, 'slot'), y.shape[1], _p(g_xt),
                                        _p(g_e), int(g_e_out is None), _p(ws), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd_inpaint')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
-def ddim_mix_bwd_inpaint_px(xt, e, at, at_next, y, mask_words, prefix, g_e_out=None):
+def ddim_mix_bwd_inpaint_px(xt, e, at, at_next, y, mask_words, prefix, g_e_out=None, loss_out=None):
     """Whole-pixel-mask form of ddim_mix_bwd_inpaint: bit mask + prefix counts instead of the dense slot map."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
@@ -160,10 +181,10 @@ def ddim_mix_bwd_inpaint_px(xt, e, at, at_next, y, mask_words, prefix, g_e_out=N
                                           _p(prefix, torch.int32, 'prefix'), y.shape[1], _p(g_xt), _p(g_e),
                                           int(g_e_out is None), _p(ws), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd_inpaint_px')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
-def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None):
+def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None, loss_out=None):
     """Last-step VJP fused with the super-resolution data term -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
@@ -178,19 +199,22 @@ def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None):
     rc = lib.nhmc_ddim_mix_bwd_sr(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                   _p(y, torch.float32, 'y'), ratio, _p(g_xt), _p(g_e), _p(ws), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd_sr')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
 # ---- a12-a15 --------------------------------------------------------------------------------
-def sum_partials(ws, tiles, n_chains, stride=1, offset=0):
+def sum_partials(ws, tiles, n_chains, stride=1, offset=0, out=None):
     lib = _lib.load()
-    out = torch.empty(n_chains, dtype=torch.float64, device=ws.device)
+    if out is None:
+        out = torch.empty(n_chains, dtype=torch.float64, device=ws.device)
+    elif out.numel() != n_chains or out.dtype != torch.float64:
+        raise _lib.NhmcError('sum_partials: out must be float64 of length n_chains')
     _lib.check(lib.nhmc_sum_partials(_p(ws, torch.float64), tiles, stride, offset, n_chains, _p(out), _stream()),
                'nhmc_sum_partials')
     return out
 
 
-def data_inpaint(xt, y, slot, apply_clip=True):
+def data_inpaint(xt, y, slot, apply_clip=True, loss_out=None):
     """-> (loss [B] float64, g_xt).  slot: int32 [N] CHW map into y (-1 = masked)."""
     lib = _lib.load()
     B, N = _chains_elems(xt)
@@ -203,7 +227,7 @@ def data_inpaint(xt, y, slot, apply_clip=True):
     rc = lib.nhmc_data_inpaint(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(slot, torch.int32, 'slot'),
                                int(apply_clip), _p(g), _p(ws), B, N, M, _stream())
     _lib.check(rc, 'nhmc_data_inpaint')
-    return sum_partials(ws, tiles, B), g
+    return sum_partials(ws, tiles, B, out=loss_out), g
 
 
 def inpaint_H(x, kept_chw):
@@ -225,7 +249,7 @@ def inpaint_Ht(y, slot, n_elem):
     return x
 
 
-def data_sr(xt, y, ratio, apply_clip=True):
+def data_sr(xt, y, ratio, apply_clip=True, loss_out=None):
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
     if xt.shape[3] != dim:
@@ -236,7 +260,7 @@ def data_sr(xt, y, ratio, apply_clip=True):
     rc = lib.nhmc_data_sr(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), ratio, int(apply_clip), _p(g),
                           _p(ws), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_sr')
-    return sum_partials(ws, tiles, B), g
+    return sum_partials(ws, tiles, B, out=loss_out), g
 
 
 def sr_H(x, ratio):
@@ -261,7 +285,7 @@ def _host_w(w):
     return C.cast(arr, C.c_void_p), arr
 
 
-def data_color(xt, y, w, apply_clip=True):
+def data_color(xt, y, w, apply_clip=True, loss_out=None):
     """w: sequence of per-channel weights (host) -> (loss [B] float64, g_xt)"""
     lib = _lib.load()
     B, Cc, hw = xt.shape[0], xt.shape[1], xt[0, 0].numel()
@@ -272,10 +296,10 @@ def data_color(xt, y, w, apply_clip=True):
     rc = lib.nhmc_data_color(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), wp, int(apply_clip), _p(g), _p(ws),
                              B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_data_color')
-    return sum_partials(ws, tiles, B), g
+    return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def ddim_mix_bwd_color(xt, e, at, at_next, y, w, g_e_out=None):
+def ddim_mix_bwd_color(xt, e, at, at_next, y, w, g_e_out=None, loss_out=None):
     """Last-step VJP fused with the colorization data term -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
@@ -288,7 +312,7 @@ def ddim_mix_bwd_color(xt, e, at, at_next, y, w, g_e_out=None):
     rc = lib.nhmc_ddim_mix_bwd_color(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                      _p(y, torch.float32, 'y'), wp, _p(g_xt), _p(g_e), _p(ws), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd_color')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
 def color_H(x, w):
@@ -329,7 +353,7 @@ def cs_Ht(y, kslot, channels, dim):
     return x.reshape(B, -1)
 
 
-def data_cs(xt, y, kslot, apply_clip=True):
+def data_cs(xt, y, kslot, apply_clip=True, loss_out=None):
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
     tiles = lib.nhmc_cs_tiles(Cc, dim)
@@ -339,10 +363,10 @@ def data_cs(xt, y, kslot, apply_clip=True):
     rc = lib.nhmc_data_cs(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(kslot, torch.int32), int(apply_clip),
                           _p(g), _p(ws), _p(tmp), B, Cc, dim, y.shape[1], _stream())
     _lib.check(rc, 'nhmc_data_cs')
-    return sum_partials(ws, tiles, B), g
+    return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_cs_vjp(xt_next, y, kslot, xt, e, at, at_next, g_e_out=None):
+def data_cs_vjp(xt_next, y, kslot, xt, e, at, at_next, g_e_out=None, loss_out=None):
     """Walsh-Hadamard CS data term on the clipped decode + VJP of the last DDIM step in the last column pass
     -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
@@ -358,7 +382,7 @@ def data_cs_vjp(xt_next, y, kslot, xt, e, at, at_next, g_e_out=None):
                               _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next), _p(g_xt),
                               _p(g_e), _p(ws), _p(tmp), B, Cc, dim, y.shape[1], _stream())
     _lib.check(rc, 'nhmc_data_cs_vjp')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
 def spectral_apply(x, L, R, Dmap, LoT, RoT):
@@ -388,7 +412,7 @@ def sandwich_rect(x, S1, S2):
     return out
 
 
-def data_srconv(xt, y, At, A, apply_clip=True):
+def data_srconv(xt, y, At, A, apply_clip=True, loss_out=None):
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
     sd = A.shape[0]
@@ -399,10 +423,10 @@ def data_srconv(xt, y, At, A, apply_clip=True):
     rc = lib.nhmc_data_srconv(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(At, torch.float32), _p(A, torch.float32),
                               int(apply_clip), _p(g), _p(ws), _p(tmp), B, Cc, dim, sd, _stream())
     _lib.check(rc, 'nhmc_data_srconv')
-    return sum_partials(ws, tiles, B), g
+    return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_srconv_vjp(xt_next, y, At, A, xt, e, at, at_next, g_e_out=None):
+def data_srconv_vjp(xt_next, y, At, A, xt, e, at, at_next, g_e_out=None, loss_out=None):
     """Bicubic / strided-convolution data term on the clipped decode + VJP of the last DDIM step in the last product's
     epilogue -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
@@ -418,10 +442,10 @@ def data_srconv_vjp(xt_next, y, At, A, xt, e, at, at_next, g_e_out=None):
                                   _p(A, torch.float32), _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec,
                                   _p(at), _p(at_next), _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, sd, _stream())
     _lib.check(rc, 'nhmc_data_srconv_vjp')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
-def data_spectral(xt, y, factors, Dmap, apply_clip=True):
+def data_spectral(xt, y, factors, Dmap, apply_clip=True, loss_out=None):
     """factors: packed [8,d,d] = U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T -> (loss [B] float64, g_xt)"""
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
@@ -433,10 +457,10 @@ def data_spectral(xt, y, factors, Dmap, apply_clip=True):
                                 _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32), int(apply_clip),
                                 _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_spectral')
-    return sum_partials(ws, tiles, B), g
+    return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None):
+def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None, loss_out=None):
     """Spectral data term on the clipped decode `xt_next` + VJP of the last DDIM step (inputs xt, e) in the last
     product's epilogue -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
@@ -453,7 +477,7 @@ def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=Non
                                     _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                     _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_spectral_vjp')
-    return sum_partials(ws, tiles, B), g_xt, g_e
+    return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
 # ---- a5-a7 ----------------------------------------------------------------------------------
@@ -564,6 +588,20 @@ def schedule_begin_mass(state, sigma_table, burn, epochs, sampling):
                                       _p(state['welford_on'], torch.int32), _p(sigma_table, torch.float64), burn, epochs,
                                       sampling, B, _stream())
     _lib.check(rc, 'nhmc_schedule_begin_mass')
+
+
+def vq_nearest(z, codebook):
+    """z [B, D, h, w], codebook [n_embed, D] -> (z_q = z + (e[k*] - z), k* int32 [B, h, w])."""
+    lib = _lib.load()
+    B, Dd = z.shape[0], z.shape[1]
+    hw = z[0, 0].numel()
+    if codebook.dim() != 2 or codebook.shape[1] != Dd:
+        raise _lib.NhmcError(f'codebook {tuple(codebook.shape)} does not match latent channels {Dd}')
+    zq = torch.empty_like(z)
+    idx = torch.empty((B,) + tuple(z.shape[2:]), dtype=torch.int32, device=z.device)
+    _lib.check(lib.nhmc_vq_nearest(_p(z, torch.float32, 'z'), _p(codebook, torch.float32, 'codebook'), _p(zq), _p(idx),
+                                   B, Dd, hw, codebook.shape[0], _stream()), 'nhmc_vq_nearest')
+    return zq, idx
 
 
 def psnr(xt, x_orig):

@@ -35,7 +35,7 @@ class H_functions:
     def H_pinv(self, vec):
         raise NotImplementedError()
 
-    def data_term(self, xt, y, apply_clip=True):
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
         raise NotImplementedError()
 
     def is_linear(self):
@@ -87,14 +87,14 @@ class Inpainting(H_functions):
 
     H_pinv = Ht
 
-    def data_term(self, xt, y, apply_clip=True):
-        return K.data_inpaint(xt, y, self.slot, apply_clip)
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
+        return K.data_inpaint(xt, y, self.slot, apply_clip, loss_out=loss_out)
 
-    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, loss_out=None):
         """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
         if self.mask_words is not None:
-            return K.ddim_mix_bwd_inpaint_px(xt_in, e, at, at_next, y, self.mask_words, self.mask_prefix, g_e_out=g_e_out)
-        return K.ddim_mix_bwd_inpaint(xt_in, e, at, at_next, y, self.slot, g_e_out=g_e_out)
+            return K.ddim_mix_bwd_inpaint_px(xt_in, e, at, at_next, y, self.mask_words, self.mask_prefix, g_e_out=g_e_out, loss_out=loss_out)
+        return K.ddim_mix_bwd_inpaint(xt_in, e, at, at_next, y, self.slot, g_e_out=g_e_out, loss_out=loss_out)
 
 
 class SuperResolution(H_functions):
@@ -122,12 +122,12 @@ class SuperResolution(H_functions):
     def H_pinv(self, vec):
         return K.sr_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.ratio, self.channels, self.img_dim, 1.0)
 
-    def data_term(self, xt, y, apply_clip=True):
-        return K.data_sr(xt, y, self.ratio, apply_clip)
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
+        return K.data_sr(xt, y, self.ratio, apply_clip, loss_out=loss_out)
 
-    def _fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
+    def _fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, loss_out=None):
         """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
-        return K.ddim_mix_bwd_sr(xt_in, e, at, at_next, y, self.ratio, g_e_out=g_e_out)
+        return K.ddim_mix_bwd_sr(xt_in, e, at, at_next, y, self.ratio, g_e_out=g_e_out, loss_out=loss_out)
 
 
 def _band_matrix(kernel, img_dim):
@@ -147,24 +147,29 @@ class Deblurring2D(H_functions):
 
     The reference tiles the sorted singular values (:519-520) while its Vt() interleaves channels
     (:493-499); the operator it really computes is out_c = U1 (D_c o (V1^T X_c V2)) U2^T with
-    D_c[perm[k]] = s_sorted[(3k+c) mod d^2].  `__init__` rebuilds that from the two 1-D kernels
-    (stable sort, so the instance is reproducible); `from_factors` takes exported operator data.
+    D_c[perm[k]] = s_sorted[(3k+c) mod d^2].  Because D is misaligned with the true singular values, the operator
+    depends on the individual singular vectors and on how the sort orders the tied (zeroed) products -- it is only
+    defined up to the torch build and host that construct it.  `__init__` therefore issues the reference's own calls
+    on the host -- `torch.svd(H, some=False)` (:473-474) and the default, unstable `sort(descending=True)` (:481) --
+    which reproduces the reference's CPU-built operator position by position under the same torch build
+    (tests/test_aniso_256_cpu.py: bit-identical factors and D at 256 x 256; a stable sort instead moves H(x) by 10 %).
+    `from_factors` takes exported operator data (a reference instance built elsewhere, e.g. on its GPU).
     """
 
     def __init__(self, kernel1, kernel2, channels, img_dim, device, zero=3e-2):
         H1, H2 = _band_matrix(kernel1.detach().cpu().float(), img_dim), _band_matrix(kernel2.detach().cpu().float(), img_dim)
-        U1, s1, V1h = torch.linalg.svd(H1)
-        U2, s2, V2h = torch.linalg.svd(H2)
-        s1 = torch.where(s1 < zero, torch.zeros_like(s1), s1)
-        s2 = torch.where(s2 < zero, torch.zeros_like(s2), s2)
-        prod = torch.outer(s1, s2).reshape(-1)
-        s_sorted, perm = prod.sort(descending=True, stable=True)
+        U1, s1, V1 = torch.svd(H1, some=False)
+        U2, s2, V2 = torch.svd(H2, some=False)
+        s1[s1 < zero] = 0
+        s2[s2 < zero] = 0
+        prod = torch.matmul(s1.reshape(img_dim, 1), s2.reshape(1, img_dim)).reshape(img_dim ** 2)
+        s_sorted, perm = prod.sort(descending=True)                         # default (unstable) sort, as Hfuncs.py:481
         hw = img_dim * img_dim
         k = torch.arange(hw)
         D = torch.zeros(channels, hw)
         for c in range(channels):
             D[c, perm] = s_sorted[(channels * k + c) % hw]
-        self._init_factors(U1, U2, V1h.t().contiguous(), V2h.t().contiguous(), D.reshape(channels, img_dim, img_dim), device)
+        self._init_factors(U1, U2, V1, V2, D.reshape(channels, img_dim, img_dim), device)
 
     @classmethod
     def from_factors(cls, U1, U2, V1, V2, D, device):
@@ -200,18 +205,18 @@ class Deblurring2D(H_functions):
         y = _img(vec, self.channels, self.img_dim)
         return K.spectral_apply(y, self._f(0), self._f(1), self.Dpinv, self._f(6), self._f(7)).reshape(y.shape[0], -1)
 
-    def data_term(self, xt, y, apply_clip=True):
-        return K.data_spectral(xt, y.reshape(xt.shape).contiguous(), self.factors, self.Dmap, apply_clip)
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
+        return K.data_spectral(xt, y.reshape(xt.shape).contiguous(), self.factors, self.Dmap, apply_clip, loss_out=loss_out)
 
     fused_wants_decode = True              # the engine hands over the clipped decode it already holds
 
-    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None):
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None, loss_out=None):
         """Data term + VJP of the last DDIM step (applied in the last product's epilogue) -> (loss, g_xt, g_e).
         xt_next: the clipped decode of that step (recomputed when the caller does not have it)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
         return K.data_spectral_vjp(xt_next, y.reshape(xt_in.shape).contiguous(), self.factors, self.Dmap, xt_in, e, at,
-                                   at_next, g_e_out=g_e_out)
+                                   at_next, g_e_out=g_e_out, loss_out=loss_out)
 
 
 class Deblurring(Deblurring2D):
@@ -245,12 +250,12 @@ class Colorization(H_functions):
     def H_pinv(self, vec):
         return K.color_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.w_pinv, self.channels)
 
-    def data_term(self, xt, y, apply_clip=True):
-        return K.data_color(xt, y, self.w, apply_clip)
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
+        return K.data_color(xt, y, self.w, apply_clip, loss_out=loss_out)
 
-    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None):
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, loss_out=None):
         """Data term + VJP of the last DDIM step in one kernel -> (loss, g_xt, g_e); used by the sampler's engine."""
-        return K.ddim_mix_bwd_color(xt_in, e, at, at_next, y.contiguous(), self.w, g_e_out=g_e_out)
+        return K.ddim_mix_bwd_color(xt_in, e, at, at_next, y.contiguous(), self.w, g_e_out=g_e_out, loss_out=loss_out)
 
 
 class WalshHadamardCS(H_functions):
@@ -278,16 +283,16 @@ class WalshHadamardCS(H_functions):
 
     H_pinv = Ht
 
-    def data_term(self, xt, y, apply_clip=True):
-        return K.data_cs(xt, y, self.kslot, apply_clip)
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
+        return K.data_cs(xt, y, self.kslot, apply_clip, loss_out=loss_out)
 
     fused_wants_decode = True
 
-    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None):
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None, loss_out=None):
         """Data term + VJP of the last DDIM step (in the last column pass) -> (loss, g_xt, g_e)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
-        return K.data_cs_vjp(xt_next, y.contiguous(), self.kslot, xt_in, e, at, at_next, g_e_out=g_e_out)
+        return K.data_cs_vjp(xt_next, y.contiguous(), self.kslot, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
 
 
 def strided_conv_matrix(kernel, img_dim, stride):
@@ -336,16 +341,16 @@ class SRConv(H_functions):
         B = vec.shape[0]
         return K.sandwich_rect(self._planes(vec, self.small_dim), self.ApT, self.ApT).reshape(B, -1)   # A+ Y A+^T
 
-    def data_term(self, xt, y, apply_clip=True):
-        return K.data_srconv(xt, y.contiguous(), self.At, self.A, apply_clip)
+    def data_term(self, xt, y, apply_clip=True, loss_out=None):
+        return K.data_srconv(xt, y.contiguous(), self.At, self.A, apply_clip, loss_out=loss_out)
 
     fused_wants_decode = True
 
-    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None):
+    def fused_last_vjp(self, xt_in, e, at, at_next, y, g_e_out=None, xt_next=None, loss_out=None):
         """Data term + VJP of the last DDIM step (in the last product's epilogue) -> (loss, g_xt, g_e)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
-        return K.data_srconv_vjp(xt_next, y.contiguous(), self.At, self.A, xt_in, e, at, at_next, g_e_out=g_e_out)
+        return K.data_srconv_vjp(xt_next, y.contiguous(), self.At, self.A, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
 
 
 def bicubic_taps(factor, a=-0.5):

@@ -103,6 +103,8 @@ class LeapfrogEngine:
         self.fuse_last = True                  # use operator.fused_last_vjp when it exists (inpainting)
         self._graphs = {}                      # (n, shape of y) -> captured decode+gradient of one chunk
         self._ge = {}                          # score-output shape -> persistent g_e buffers (sigma-channels stay zero)
+        self._outs = None                      # batch-wide decode / loss buffers of `step`
+        self.update_events = None              # bench: list collecting (start, end, chains) event pairs of each update launch
         steps = list(zip(reversed(seq), reversed(seq_next)))
         from .schedule import alpha_bar_table
         table = alpha_table.to(device).float() if alpha_table is not None else alpha_bar_table(b)
@@ -116,47 +118,90 @@ class LeapfrogEngine:
         c = self.chunk or B
         return [(s, min(B, s + c)) for s in range(0, B, c)]
 
+    def _out_buffers(self, x):
+        """Batch-wide decode / loss buffers, kept per shape: the kernels of every chunk write their slice directly."""
+        key = (tuple(x.shape), x.device)
+        if self._outs is None or self._outs[0] != key:
+            self._outs = (key, torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float64, device=x.device))
+        return self._outs[1], self._outs[2]
+
     def decode_and_grad(self, x, y, graph=False):
         """-> xt [B,C,H,W] (clipped decode), loss [B] fp64, (g_direct, g_score): the two pieces of
-        d(sum_b loss_b)/dx, summed later inside the consuming kernel.
+        d(sum_b loss_b)/dx, summed later inside the consuming kernel (g_score is None for a score evaluated
+        without gradient).  Batch-wide tensors: with more than one chunk the per-chunk gradients are gathered by a
+        copy -- the sampler itself uses `step`, which hands each chunk's gradients straight to the fused update.
 
         graph=True replays one hipGraph per chunk (score network forward + input-gradient included) instead of
         launching its ~10^3 kernels from Python: same kernels, same results; pays off when a chunk is small
         (the reference's one-chain operating point), where the step is launch-bound."""
         B = x.shape[0]
         xt_out = torch.empty_like(x)
-        ga, gb = torch.empty_like(x), torch.empty_like(x)
         loss = torch.empty(B, dtype=torch.float64, device=x.device)
-        for lo, hi in self._chunks(B):
-            run = self._graphed_chunk if graph else self._decode_and_grad_chunk
-            run(x[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi], ga[lo:hi], gb[lo:hi])
+        chunks = self._chunks(B)
+        run = self._graphed_chunk if graph else self._decode_and_grad_chunk
+        if len(chunks) == 1 and not graph:
+            ga, gb = run(x, y, xt_out, loss)
+            return xt_out, loss, ga, gb
+        ga, gb = torch.empty_like(x), None
+        for lo, hi in chunks:
+            a, b_ = run(x[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi])
+            ga[lo:hi].copy_(a)
+            if b_ is not None:
+                gb = torch.empty_like(x) if gb is None else gb
+                gb[lo:hi].copy_(b_)
         return xt_out, loss, ga, gb
 
-    def _graphed_chunk(self, x, y, xt_out, loss_out, ga_out, gb_out):
+    def step(self, mode, x_in, x, p, y, eps, sigma_y, m_inv, ws, graph=False):
+        """Decode + gradient at x_in, then the fused leapfrog update of (x, p), chunk by chunk: every kernel writes
+        its slice of the batch-wide outputs and each chunk's two gradient pieces go straight into the update --
+        no gather copies, no clone of the position.  mode FIRST: out of place (x_in -> x, x_in kept); MID / LAST:
+        x_in is x.  -> (xt, loss): batch-wide buffers owned by the engine, valid until the next step."""
+        B, N = x.shape[0], x[0].numel()
+        xt_out, loss = self._out_buffers(x)
+        tiles2 = 2 * K.leapfrog_tiles(N)
+        run = self._graphed_chunk if graph else self._decode_and_grad_chunk
+        for lo, hi in self._chunks(B):
+            ga, gb = run(x_in[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi])
+            w = ws[lo * tiles2: hi * tiles2]
+            if self.update_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), hi - lo)
+                ev[0].record()
+            if mode == K.LF_FIRST:
+                K.leapfrog_first(x_in[lo:hi], x[lo:hi], p[lo:hi], ga, eps[lo:hi], sigma_y[lo:hi], m_inv, w, g2=gb)
+            else:
+                K.leapfrog_fused(mode, x[lo:hi], p[lo:hi], ga, eps[lo:hi], sigma_y[lo:hi], m_inv, w, g2=gb)
+            if self.update_events is not None:
+                ev[1].record()
+                self.update_events.append(ev)
+        return xt_out, loss
+
+    def _graphed_chunk(self, x, y, xt_out, loss_out):
         key = (tuple(x.shape), tuple(y.shape))
         rec = self._graphs.get(key)
         if rec is None:
             sx, sy = x.clone(), y.clone()
-            outs = (torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float64, device=x.device),
-                    torch.empty_like(x), torch.empty_like(x))
+            sxt, sloss = torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up: solver selection, allocator pools
                 for _ in range(2):
-                    self._decode_and_grad_chunk(sx, sy, *outs)
+                    self._decode_and_grad_chunk(sx, sy, sxt, sloss)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._decode_and_grad_chunk(sx, sy, *outs)
-            rec = self._graphs[key] = (g, sx, sy, outs)
-        g, sx, sy, outs = rec
+                grads = self._decode_and_grad_chunk(sx, sy, sxt, sloss)
+            rec = self._graphs[key] = (g, sx, sy, sxt, sloss, grads)
+        g, sx, sy, sxt, sloss, grads = rec
         sx.copy_(x)
         sy.copy_(y)
         g.replay()
-        for dst, src in zip((xt_out, loss_out, ga_out, gb_out), outs):
-            dst.copy_(src)
+        xt_out.copy_(sxt)
+        loss_out.copy_(sloss)
+        return grads                                            # the graph's own buffers: valid until its next replay
 
-    def _decode_and_grad_chunk(self, x, y, xt_out, loss_out, ga_out, gb_out):
+    def _decode_and_grad_chunk(self, x, y, xt_out, loss_out):
+        """Writes the clipped decode and the per-chain loss of this chunk into xt_out / loss_out (views of the
+        batch-wide buffers) and returns the chunk's gradient pieces (g_direct, g_score or None)."""
         n = x.shape[0]
         S = self.n_steps
         ins, outs = [], []
@@ -168,47 +213,53 @@ class LeapfrogEngine:
                 e = self.score(leaf, t)
             e_c = e.detach() if e.is_contiguous() else e.detach().contiguous()
             cur = K.ddim_mix_fwd(leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
-                                 final_clip=(s == S - 1))['xt_next']
+                                 final_clip=(s == S - 1), out=xt_out if s == S - 1 else None)['xt_next']
             ins.append((leaf, e_c))
-            outs.append(e)
-        xt_out.copy_(cur)
-        fused = self.image_map is None and self.fuse_last and hasattr(self.operator, 'fused_last_vjp')
+            outs.append(e if e.requires_grad else None)           # None: score evaluated without gradient (latent model)
+        fused = self.image_map is None and self.fuse_last and hasattr(self.operator, 'fused_last_vjp') \
+            and outs[S - 1] is not None
         # the final clip is applied by the last mix; its mask is re-derived inside the last mix backward
         if fused:
-            l = g = None
+            g = None
         elif self.image_map is None:
-            l, g = self.operator.data_term(cur, y, apply_clip=False)
+            _, g = self.operator.data_term(cur, y, apply_clip=False, loss_out=loss_out)
         else:
             zleaf = cur.detach().requires_grad_(True)
             with torch.enable_grad():
                 img = self.image_map(zleaf)
-            l, g_img = self.operator.data_term(img.detach().contiguous(), y, apply_clip=False)
+            img_c = img.detach()
+            _, g_img = self.operator.data_term(img_c if img_c.is_contiguous() else img_c.contiguous(), y,
+                                               apply_clip=False, loss_out=loss_out)
             (g,) = torch.autograd.grad(img, zleaf, g_img)
-            g = g.contiguous()
-        if not fused:
-            loss_out.copy_(l)
+            g = g if g.is_contiguous() else g.contiguous()
         g2 = None
         # one persistent score-gradient buffer per DDIM step and shape: its sigma-channels are zeroed once and never
         # rewritten (the mix VJP writes only the first C channels: -T of traffic per step)
-        key = tuple(ins[0][1].shape)
-        bufs = self._ge.get(key)
-        if bufs is None:
-            bufs = self._ge[key] = [torch.zeros_like(ins[0][1]) for _ in range(S)]
+        bufs = None
+        if any(o is not None for o in outs):
+            key = tuple(ins[0][1].shape)
+            bufs = self._ge.get(key)
+            if bufs is None:
+                bufs = self._ge[key] = [torch.zeros_like(ins[0][1]) for _ in range(S)]
         for s in reversed(range(S)):
             leaf, e_c = ins[s]
             if fused and s == S - 1:                  # data term + last-step VJP in one kernel
                 extra = dict(xt_next=cur) if getattr(self.operator, 'fused_wants_decode', False) else {}
-                l, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, self.at[s].expand(n),
-                                                                self.at_next[s].expand(n), y, g_e_out=bufs[s], **extra)
-                loss_out.copy_(l)
+                _, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, self.at[s].expand(n),
+                                                                self.at_next[s].expand(n), y, g_e_out=bufs[s],
+                                                                loss_out=loss_out, **extra)
             else:
                 g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
-                                               final_clip=(s == S - 1), gout2=g2, g_e_out=bufs[s])
-            (g_score,) = torch.autograd.grad(outs[s], leaf, g_e)
-            outs[s] = None
-            g, g2 = g_direct, g_score.contiguous()
-        ga_out.copy_(g)
-        gb_out.copy_(g2)
+                                               final_clip=(s == S - 1), gout2=g2, want_g_e=outs[s] is not None,
+                                               g_e_out=bufs[s] if outs[s] is not None else None)
+            if outs[s] is not None:
+                (g_score,) = torch.autograd.grad(outs[s], leaf, g_e)
+                outs[s] = None
+                g2 = g_score if g_score.is_contiguous() else g_score.contiguous()
+            else:
+                g2 = None
+            g = g_direct
+        return g, g2
 
     @torch.no_grad()
     def decode(self, x):
@@ -242,20 +293,19 @@ class ChainState:
         return self.t.get(k, default)
 
 
-def run_trajectory(engine, x, p, y, state, m, L, ws=None, graph=False):
-    """One outer iteration (main_sampling.py:693-718) for all chains.  x is NOT modified.
-    -> dict(x_prop, p, xt, loss, H0, H1)"""
+def run_trajectory(engine, x, p, y, state, m, L, ws=None, graph=False, x_prop=None):
+    """One outer iteration (main_sampling.py:693-718) for all chains.  x is NOT modified; p is updated in place.
+    x_prop: optional buffer for the proposal (kept by the caller across trajectories; allocated here otherwise).
+    -> dict(x_prop, p, xt, loss, H0, H1); xt / loss are the engine's buffers, valid until its next step."""
     B, N = x.shape[0], x[0].numel()
     m_inv = m ** (-1)
     eps, sig = state['eps_eff'], state['sigma_y']
     ws = ws if ws is not None else K.leapfrog_ws(B, N, x.device)
-    xt, loss, ga, gb = engine.decode_and_grad(x, y, graph=graph)
-    x_prop = x.clone()
-    K.leapfrog_fused(K.LF_FIRST, x_prop, p, ga, eps, sig, m_inv, ws, g2=gb)
+    x_prop = x_prop if x_prop is not None else torch.empty_like(x)
+    xt, loss = engine.step(K.LF_FIRST, x, x_prop, p, y, eps, sig, m_inv, ws, graph=graph)
     H0 = K.hamiltonian(ws, N, loss, sig, m_inv)
     for l in range(L):
-        xt, loss, ga, gb = engine.decode_and_grad(x_prop, y, graph=graph)
-        K.leapfrog_fused(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, p, ga, eps, sig, m_inv, ws, g2=gb)
+        xt, loss = engine.step(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, x_prop, p, y, eps, sig, m_inv, ws, graph=graph)
     H1 = K.hamiltonian(ws, N, loss, sig, m_inv)
     return dict(x_prop=x_prop, p=p, xt=xt, loss=loss, H0=H0, H1=H1)
 
@@ -289,12 +339,13 @@ def hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noi
     samples = torch.zeros((B, sampling) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
     xt_last = torch.zeros_like(x)
     ws = K.leapfrog_ws(B, N, device)
+    x_prop = torch.empty_like(x)
     trace = [] if collect_trace else None
     it = 0
     while True:
         K.schedule_begin(state, sigma_0, epochs, sampling)
         p = noise.momentum(it, x, math.sqrt(m))
-        out = run_trajectory(engine, x, p, y_0, state, m, L, ws, graph=graph)
+        out = run_trajectory(engine, x, p, y_0, state, m, L, ws, graph=graph, x_prop=x_prop)
         u = noise.uniform(it, B, device)
         accept, dH = K.metropolis(out['H0'], out['H1'], u, state['active'])
         K.accept_commit(accept, state['epoch'], x, out['x_prop'], out['xt'], samples, epochs, sampling)
@@ -458,11 +509,12 @@ def hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *,
     ring = torch.zeros((B, sampling) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
     xt_last = torch.zeros_like(x)
     ws = K.leapfrog_ws(B, N, device)
+    x_prop = torch.empty_like(x)
     trace = [] if collect_trace else None
     for epoch in range(epochs + 2 * sampling):
         st['eps_eff'].copy_(st['eps'])
         p = noise.momentum(epoch, x, math.sqrt(m))
-        out = run_trajectory(engine, x, p, y_0, st, m, L, ws)
+        out = run_trajectory(engine, x, p, y_0, st, m, L, ws, x_prop=x_prop)
         u = noise.uniform(epoch, B, device)
         accept, dH = K.metropolis(out['H0'], out['H1'], u, None)
         final = epoch >= epochs

@@ -29,22 +29,33 @@ def get_beta_schedule(beta_schedule='linear', *, beta_start=1e-4, beta_end=2e-2,
     return betas
 
 
-_tables = {}
+_tables = {}          # id(betas tensor) -> (weakref to it, its version counter, table on its device)
+_builds = 0
+
+
+def table_builds():
+    """How many times a table was built (tests: the plugin-surface decode must not rebuild / re-sync per call)."""
+    return _builds
 
 
 def alpha_bar_table(b):
-    """fp32 table on b's device, entry k = alpha-bar at t = k-1 (entry 0 = 1).  Cached by the betas' VALUES (the
-    host copy is needed for the product anyway), so a recycled device address can never return a stale table."""
+    """fp32 table on b's device, entry k = alpha-bar at t = k-1 (entry 0 = 1): the sequential fp32 product on the CPU,
+    bit-identical to the reference's CPU result.  Building it copies the betas to the host (a sync), so it is cached per
+    LIVE tensor object and version counter: the same betas tensor handed in again (six times per decode by the
+    plugin-surface `iterative_sampling`) costs a dictionary lookup, an in-place edit or a new tensor rebuilds, and a
+    recycled address can never return a stale table because the weak reference dies with the tensor."""
+    global _builds
+    hit = _tables.get(id(b))
+    if hit is not None and hit[0]() is b and hit[1] == b._version:
+        return hit[2]
+    import weakref
     host = b.detach().float().cpu()
-    key = (str(b.device), host.numpy().tobytes())
-    hit = _tables.get(key)
-    if hit is None:
-        table = (1 - torch.cat([torch.zeros(1), host])).cumprod(dim=0)
-        hit = table.to(b.device)
-        if len(_tables) > 16:
-            _tables.clear()
-        _tables[key] = hit
-    return hit
+    table = (1 - torch.cat([torch.zeros(1), host])).cumprod(dim=0).to(b.device)
+    _builds += 1
+    for k in [k for k, v in _tables.items() if v[0]() is None]:
+        del _tables[k]
+    _tables[id(b)] = (weakref.ref(b), b._version, table)
+    return table
 
 
 def compute_alpha(beta, t):

@@ -248,6 +248,33 @@ def g5_ops_256(ms):
     save('g5_ops_256.npz', **arrays)
 
 
+def g13_aniso_256(ms):
+    """deblur_aniso at BASELINE size: the reference object's operator data (U1,U2,V1,V2 and the sort permutation, from
+    which D follows) and probes of H, Ht, H_pinv -- what pins configs[3]'s operator position by position."""
+    from obs_functions.Hfuncs import Deblurring2D
+    k1, k2 = aniso_kernels()
+    torch.set_num_threads(4)      # LAPACK's blocking -- hence the near-null singular vectors -- depends on it; G5 used 4 too
+    db = Deblurring2D(k1, k2, 3, 256, 'cpu')
+    ex = export_aniso(db)
+    g = torch.Generator().manual_seed(1313)
+    x = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    y = torch.randn(2, 3 * 256 * 256, generator=g)
+    hx, hty, hpy = db.H(x), db.Ht(y.clone()), db.H_pinv(y.clone()).reshape(2, -1)
+    pm = torch.randperm(hx.shape[1], generator=g)[:512]
+    arrays = dict(U1=ex['U1'], U2=ex['U2'], V1=ex['V1'], V2=ex['V2'], perm=ex['perm'].astype(np.uint16),
+                  s1=np32(db.singulars_small1), s2=np32(db.singulars_small2), s_sorted=ex['s_sorted'],
+                  kernel1=np32(k1), kernel2=np32(k2), xy_seed=np.array(1313), num_threads=np.array(torch.get_num_threads()), probe=np32(pm).astype(np.int32),
+                  Hx_probe=np32(hx[:, pm]), Hty_probe=np32(hty[:, pm]), Hpinv_probe=np32(hpy[:, pm]),
+                  Hx_norm=np32(hx.double().norm(dim=1)), Hty_norm=np32(hty.double().norm(dim=1)),
+                  Hpinv_norm=np32(hpy.double().norm(dim=1)))
+    assert int(ex['perm'].max()) < 65536
+    save('g13_aniso_256.npz', **arrays)
+
+
+if __name__ == '__main__' and 'g13' in sys.argv[1:]:
+    g13_aniso_256(import_reference())
+    sys.exit(0)
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
     ms = import_reference()
@@ -284,11 +311,14 @@ def g6_unet(ms):
     t = torch.tensor([750.0, 250.0])
     with torch.no_grad():
         out = net(x, t)
+    gout = torch.randn(out.shape, generator=g)                     # input gradient (what the HMC backward asks of the net)
+    xl = x.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(net(xl, t), xl, gout)
     with contextlib.redirect_stdout(io.StringIO()):
         full = create_model(**{**cfg, 'image_size': 256, 'num_channels': 128, 'num_head_channels': 64})
     keys_small = '\n'.join(f'{k} {tuple(v.shape)}' for k, v in net.state_dict().items())
     keys_full = '\n'.join(f'{k} {tuple(v.shape)}' for k, v in full.state_dict().items())
-    save('g6_unet_64.npz', x=np32(x), t=np32(t), out=np32(out), weight_seed=np.array(606), weight_scale=np.array(0.05),
+    save('g6_unet_64.npz', x=np32(x), t=np32(t), out=np32(out), gout=np32(gout), gx=np32(gx), weight_seed=np.array(606), weight_scale=np.array(0.05),
          keys_small_sha256=np.array(hashlib.sha256(keys_small.encode()).hexdigest()),
          keys_ffhq_sha256=np.array(hashlib.sha256(keys_full.encode()).hexdigest()),
          n_params_ffhq=np.array(sum(v.numel() for v in full.state_dict().values())))

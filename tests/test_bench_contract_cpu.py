@@ -13,10 +13,13 @@ def test_flags_and_defaults(monkeypatch):
     import bench
     monkeypatch.setattr(sys, 'argv', ['bench.py'])
     a = bench.parse()
-    assert (a.gpus, a.batch, a.deg) == (1, 64, 'inpaint_random') and 1 <= a.steps <= 10 and a.warmup >= 1
+    assert (a.gpus, a.batch or bench.B_PER_GPU, a.deg, a.latent) == (1, 64, 'inpaint_random', False) and 1 <= a.steps <= 10 and a.warmup >= 1
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '5', '--warmup', '2'])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--latent'])
+    a = bench.parse()
+    assert a.latent and (a.batch or bench.B_LATENT) == 16                        # configs[4]: 128 chains over 8 GPUs
 
 
 def test_json_line_carries_the_contract_keys():

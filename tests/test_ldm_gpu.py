@@ -1,0 +1,221 @@
+"""GPU: the latent path on nhmc.ldm's LDM U-Net + VQ first stage (BASELINE configs[4]) -- the codebook kernel, the
+networks against the reference-class fixture (G12), the sampler against the latent oracle and the reference's run."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import latent_ref, ldm_ref, operators as oops
+from tests.test_ldm_cpu import DEC_SMALL, SEQ, SEQ_NEXT, UNET_SMALL, small_model
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+class F64Product:
+    """nhmc.ldm.LatentDiffusion on the GPU with both networks evaluated in float64 (ldm_ref.F64Net); the codebook
+    lookup stays the fp32 HIP kernel.  Twin of ldm_ref.OracleLatent.from_product(model, f64=True)."""
+
+    def __init__(self, model, dev):
+        fs = model.first_stage_model
+        self.unet = ldm_ref.F64Net(model.model.diffusion_model).to(dev)
+        self.dec = ldm_ref.F64Net(torch.nn.Sequential(fs.post_quant_conv, fs.decoder)).to(dev)
+        self.m = model.to(dev)
+        self.alphas_cumprod, self.alphas_cumprod_prev = self.m.alphas_cumprod, self.m.alphas_cumprod_prev
+
+    def apply_model(self, x, t, cond=None):
+        with torch.no_grad():
+            return self.unet(x, t)
+
+    def differentiable_decode_first_stage(self, z):
+        return self.dec(self.m.first_stage_model.quantize(1. / self.m.scale_factor * z))
+
+
+def test_vq_kernel_takes_the_quantisers_decisions(golden):
+    import nhmc.kernels as K
+    g = golden('g12_ldm_16.npz')
+    dev = torch.device('cuda')
+    zq, idx = K.vq_nearest(T(g['z']).to(dev), T(g['codebook']).to(dev))
+    assert np.array_equal(idx.cpu().numpy(), g['vq_idx']) and np.array_equal(zq.cpu().numpy(), g['vq_out'])
+    gen = torch.Generator().manual_seed(8)
+    for D, n_embed, hw in ((3, 8192, 64), (4, 8192, 64), (3, 1000, 24)):          # 1000 codes: ragged last LDS chunk
+        z = torch.rand(2, D, hw, hw, generator=gen) * 2 - 1
+        cb = torch.randn(n_embed, D, generator=gen) * 0.5
+        want_q, want_i = ldm_ref.vq_straight_through(z, cb)
+        got_q, got_i = K.vq_nearest(z.to(dev), cb.to(dev))
+        # same op order as torch's CPU kernels (sequential norms, FMA-chain inner product): the SAME decisions, not
+        # merely near-tie-equivalent ones -- a single flipped code moves the decoded image and its gradient by O(1) locally
+        assert torch.equal(got_i.cpu().long(), want_i), int((got_i.cpu().long() != want_i).sum())
+        assert torch.equal(got_q.cpu(), want_q)
+    with pytest.raises(Exception, match='codebook'):
+        K.vq_nearest(torch.zeros(1, 3, 4, 4, device=dev), torch.zeros(8, 4, device=dev))
+    with pytest.raises(Exception, match='shape'):
+        K.vq_nearest(torch.zeros(1, 5, 4, 4, device=dev), torch.zeros(8, 5, device=dev))
+
+
+def test_networks_on_the_gpu_match_the_reference_classes(golden):
+    g = golden('g12_ldm_16.npz')
+    dev = torch.device('cuda')
+    m = small_model(g).to(dev)
+    with torch.no_grad():
+        out = m.apply_model(T(g['x']).to(dev), T(g['t']).to(dev), None)
+        img = m.first_stage_model.decoder(T(g['z']).to(dev))
+        full = m.decode_first_stage(T(g['z']).to(dev))
+    assert rel(out, T(g['unet_out'])) < 1e-4 and rel(img, T(g['dec_out'])) < 1e-4
+    assert rel(full, T(g['first_stage_out'])) < 1e-4
+    # straight-through gradient of the first stage reaches the latent
+    z = T(g['z']).to(dev).requires_grad_(True)
+    (gz,) = torch.autograd.grad(m.differentiable_decode_first_stage(z).sum(), z)
+    twin = ldm_ref.OracleLatent.from_product(m)
+    zc = T(g['z']).clone().requires_grad_(True)
+    (gc,) = torch.autograd.grad(twin.differentiable_decode_first_stage(zc).sum(), zc)
+    assert rel(gz, gc) < 1e-4
+
+
+def _engine(model, op, dev):
+    from nhmc import plugin, sampler
+    algo = plugin.HMCLatent(model, op, 0.1)
+    table = torch.cat([model.alphas_cumprod_prev[0:1], model.alphas_cumprod])
+    return sampler.LeapfrogEngine(algo.score, op, None, SEQ, SEQ_NEXT, dev, alpha_table=table,
+                                  image_map=model.differentiable_decode_first_stage), algo
+
+
+def test_first_trajectory_of_the_reference_ldm_run(golden):
+    """The reference's `hmc_latent` on its own UNetModel / Decoder classes (G12): first trajectory, fp32 on both sides."""
+    from nhmc import operators, sampler
+    g = golden('g12_ldm_16.npz')
+    dev = torch.device('cuda')
+    model = small_model(g).to(dev)
+    op = operators.Inpainting(3, 64, T(g['hmc_missing']).long(), dev)
+    eng, _ = _engine(model, op, dev)
+    L = max(1, int(np.floor(float(g['hmc_tau']) / float(g['hmc_epsilon']))))
+    st = sampler.ChainState(1, float(g['hmc_tau']), float(g['hmc_epsilon']), dev)
+    st['eps_eff'].fill_(float(g['hmc_epsilon']))
+    st['sigma_y'].fill_(float(g['hmc_sigma_y']))
+    got = sampler.run_trajectory(eng, T(g['hmc_x']).to(dev), T(g['hmc_p'][0]).to(dev).clone(), T(g['hmc_y_0']).to(dev), st, 1.0, L)
+    want = latent_ref.trajectory_latent(T(g['hmc_x']), T(g['hmc_p'][0]), SEQ, SEQ_NEXT, ldm_ref.OracleLatent.from_product(model),
+                                        oops.InpaintRef(3, 64, T(g['hmc_missing']).long()), T(g['hmc_y_0']),
+                                        sigma_y=float(g['hmc_sigma_y']), eps=float(g['hmc_epsilon']), m=1.0, L=L)
+    assert rel(got['x_prop'], want['x']) < 1e-4 and rel(got['xt'], want['xt']) < 1e-4 and rel(got['loss'], want['loss']) < 1e-4
+    assert abs(float((got['H1'] - got['H0'])[0]) + float(g['hmc_neg_dH'][0])) < 0.02        # the reference's own -dH
+
+
+def test_latent_loop_on_the_ldm_model_takes_the_oracles_decisions(golden):
+    """Whole 70-epoch `hmc_latent` loop on the tape the reference drew (G12), networks in float64 on both sides:
+    same accept decisions as the oracle, same returned latents; and the oracle in fp32 is pinned to the reference's
+    own run on CPU (tests/test_ldm_cpu.py)."""
+    from nhmc import operators, plugin, sampler
+    g = golden('g12_ldm_16.npz')
+    dev = torch.device('cuda')
+    base = small_model(g)
+    ref_op = oops.InpaintRef(3, 64, T(g['hmc_missing']).long())
+    op = operators.Inpainting(3, 64, T(g['hmc_missing']).long(), dev)
+    P, U = T(g['hmc_p']), T(g['hmc_u']).float()
+    kw = dict(sigma_y=float(g['hmc_sigma_y']), tau=float(g['hmc_tau']), epsilon=float(g['hmc_epsilon']), m=1.0,
+              sigma_0=float(g['hmc_sigma_0']))
+
+    class Tape:                                                   # the oracle draws through torch's global functions
+        def __init__(self):
+            self.ip = self.iu = 0
+
+        def randn_like(self, x, **k):
+            self.ip += 1
+            return P[self.ip - 1].clone()
+
+        def rand(self, *a, **k):
+            self.iu += 1
+            return U[self.iu - 1].reshape(1).clone()
+
+    tape, trace = Tape(), {}
+    real = torch.randn_like, torch.rand
+    torch.randn_like, torch.rand = tape.randn_like, tape.rand
+    try:
+        want = latent_ref.hmc_latent_reference(T(g['hmc_x']), SEQ, SEQ_NEXT, ldm_ref.OracleLatent.from_product(base, f64=True),
+                                               ref_op, T(g['hmc_y_0']), T(g['hmc_x_orig']), trace=trace, **kw)
+    finally:
+        torch.randn_like, torch.rand = real
+    algo = plugin.HMCLatent(F64Product(base, dev), op, kw['sigma_0'])
+    opt = types.SimpleNamespace(**kw)
+    res = sampler.hmc_latent_chains(T(g['hmc_x']).to(dev), SEQ, SEQ_NEXT, algo, opt, T(g['hmc_y_0']).to(dev), op,
+                                    T(g['hmc_x_orig']).to(dev),
+                                    noise=sampler.TapeNoise(lambda it: P[it], lambda it: U[it].reshape(1)), collect_trace=True)
+    got_acc = [bool(r['accept'][0]) for r in res.trace]
+    for it, (a, b) in enumerate(zip(trace['accept'], got_acc)):
+        margin = abs(float(U[it]) - min(1.0, float(np.exp(-trace['dH'][it]))))
+        assert a == b or margin < 1e-3, (it, a, b, margin)
+    assert [float(r['sigma_y'][0]) for r in res.trace] == trace['sigma_y']
+    assert res.samples[0].shape == want.shape and rel(res.samples[0], want) < 1e-4
+    # and the reference's own (fp32) decisions: identical wherever its accept probability is not within the band
+    ref_acc = [bool(u < np.exp(min(0.0, d))) for u, d in zip(g['hmc_u'], g['hmc_neg_dH'])]
+    n_prefix = next((i for i, (a, b) in enumerate(zip(ref_acc, got_acc)) if a != b), len(ref_acc))
+    assert n_prefix >= 10, n_prefix        # fp32-vs-fp64 network noise may separate the runs later, not at the start
+
+
+@pytest.mark.parametrize('C,B', [(3, 16), (4, 2)])
+def test_configs4_size_trajectory_against_the_oracle(C, B):
+    """BASELINE configs[4] geometry: [B, C, 64, 64] latents -> 256x256 image through the VQ first stage (8192 codes),
+    inpaint_random at 256x256, 16 chains per GPU; networks at a reduced width so the CPU oracle finishes in seconds
+    (C = 3 is the reference config, C = 4 is BASELINE.json's wording)."""
+    from nhmc import ldm, operators, sampler
+    dev = torch.device('cuda')
+    gen = torch.Generator().manual_seed(40 + C)
+    unet_cfg = dict(UNET_SMALL, image_size=64, in_channels=C, out_channels=C)
+    fs_cfg = dict(embed_dim=C, n_embed=8192, ddconfig=dict(DEC_SMALL, resolution=256, z_channels=C))
+    model = ldm.LatentDiffusion(unet_config=unet_cfg, first_stage_config=fs_cfg, linear_start=0.0015, linear_end=0.0195)
+    model.load_state_dict({**model.state_dict(), **ldm_ref.seeded_state(
+        {k: v for k, v in model.state_dict().items() if not k.startswith('alphas')}, 4400 + C)})
+    with torch.no_grad():
+        model.first_stage_model.decoder.conv_out.weight.mul_(0.3)
+        model.first_stage_model.quantize.embedding.weight.copy_(torch.rand(8192, C, generator=gen) * 2 - 1)
+    model = model.eval().requires_grad_(False)
+    missing = oops.random_inpaint_missing(256, generator=gen)
+    ref_op, op = oops.InpaintRef(3, 256, missing), operators.Inpainting(3, 256, missing, dev)
+    assert op.M == 15729
+    x = torch.randn(B, C, 64, 64, generator=gen)
+    p = torch.randn(B, C, 64, 64, generator=gen)
+    y = ref_op.H(torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1) + 0.1 * torch.randn(B, ref_op.M, generator=gen)
+    L = 2
+    sel = sorted({0, B // 2, B - 1})                       # chains are independent: the fp64 CPU oracle runs three of them
+    want = latent_ref.trajectory_latent(x[sel], p[sel].clone(), SEQ, SEQ_NEXT, ldm_ref.OracleLatent.from_product(model, f64=True),
+                                        ref_op, y[sel], sigma_y=1.0, eps=0.05, m=1.0, L=L)
+    eng, _ = _engine(F64Product(model, dev), op, dev)
+    eng.chunk = 8
+    st = sampler.ChainState(B, 1.0, 0.05, dev)
+    st['eps_eff'].fill_(0.05)
+    st['sigma_y'].fill_(1.0)
+    got = sampler.run_trajectory(eng, x.to(dev), p.to(dev).clone(), y.to(dev), st, 1.0, L)
+    assert got['xt'].shape == (B, C, 64, 64) and bool(torch.isfinite(got['H1']).all())
+    assert rel(got['x_prop'][sel], want['x']) < 1e-4 and rel(got['p'][sel], want['p']) < 1e-4
+    assert rel(got['xt'][sel], want['xt']) < 1e-4 and rel(got['loss'][sel], want['loss']) < 1e-4
+    assert float((got['H1'].cpu()[sel] - want['H1']).abs().max()) <= 1e-4 * float(want['H1'].abs().max())
+
+
+def test_ffhq_width_latent_model_runs_one_trajectory():
+    """The configs/config_ffhq_latent.yml architecture at full width (random init: the checkpoints are fetch-only),
+    2 chains: a trajectory completes with finite energies, and eps = 0 leaves the position where it was."""
+    from nhmc import ldm, operators, sampler
+    dev = torch.device('cuda')
+    torch.manual_seed(3)
+    model = ldm.create_latent_model(ckpt=None, quiet=True).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    op = operators.Inpainting(3, 256, oops.random_inpaint_missing(256, generator=gen), dev)
+    eng, _ = _engine(model, op, dev)
+    x = torch.randn(2, 3, 64, 64, generator=gen).to(dev)
+    p = torch.randn(2, 3, 64, 64, generator=gen).to(dev)
+    y = torch.randn(2, op.M, generator=gen).to(dev)
+    st = sampler.ChainState(2, 1.0, 0.05, dev)
+    st['sigma_y'].fill_(1.0)
+    got = sampler.run_trajectory(eng, x, p.clone(), y, st, 1.0, 1)                   # eps_eff = 0: frozen chains
+    assert torch.equal(got['x_prop'], x) and torch.equal(got['p'], p)
+    assert bool(torch.isfinite(got['H0']).all()) and torch.equal(got['H0'], got['H1'])
+    st['eps_eff'].fill_(0.05)
+    got = sampler.run_trajectory(eng, x, p.clone(), y, st, 1.0, 1)
+    assert bool(torch.isfinite(got['H1']).all()) and bool(torch.isfinite(got['xt']).all()) and not torch.equal(got['x_prop'], x)
+    img = model.decode_first_stage(got['xt'])
+    assert img.shape == (2, 3, 256, 256)
