@@ -67,19 +67,22 @@ def parse():
     ap.add_argument('--deg', default='inpaint_random',
                     help='degradation: inpaint_random (the BASELINE metric), sr4 (configs[2]), deblur_aniso (configs[3]), ...')
     ap.add_argument('--latent', action='store_true', help='BASELINE configs[4]: hmc_latent with the LDM U-Net + VQ-f4 decode in the loop')
+    ap.add_argument('--tiny-score', action='store_true',
+                    help='rehearsal only: a 32-channel U-Net of the same architecture (control-flow tests; never the metric)')
     ap.add_argument('--rehearse-shared-gpu', action='store_true',
                     help='rehearsal only: all ranks use cuda:0 over gloo (checks the N>1 control flow on a 1-GPU box)')
     return ap.parse_args()
 
 
-def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=None):
+def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=None, tiny=False):
     import nhmc.kernels as K
     from nhmc import operators, plugin, schedule, unet
     gen = torch.Generator().manual_seed(seed)
     op = operators.build_operator(deg, CH, DIM, device, generator=gen)
     if model is None:
         torch.manual_seed(seed)
-        model = unet.create_model(**unet.FFHQ_CONFIG).to(device).eval().requires_grad_(False)
+        cfg = dict(unet.FFHQ_CONFIG, num_channels=32, num_head_channels=32) if tiny else unet.FFHQ_CONFIG
+        model = unet.create_model(**cfg).to(device).eval().requires_grad_(False)
     algo = plugin.HMC(model, op, 2 * SIGMA0_CLI)
     b = torch.from_numpy(schedule.get_beta_schedule('linear', beta_start=1e-4, beta_end=0.02,
                                                     num_diffusion_timesteps=1000)).float().to(device)
@@ -378,7 +381,7 @@ def latent_main(args):
     ws = K.leapfrog_ws(B, x[0].numel(), device)
     dt, loss, _ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
     stats = torch.stack([loss.float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
-    allstats = sharding.gather_chains(stats.cpu() if args.rehearse_shared_gpu else stats, world * B, rank, world)
+    allstats = sharding.gather_chains(stats, world * B, rank, world)
     if rank == 0:
         roof = leapfrog_roofline(device, B_PER_GPU, args.roofline_launches)
         # the HIP kernel this path adds: codebook lookup of all 16 x 4096 latent pixels against 8192 codes
@@ -439,7 +442,7 @@ def main():
     device = torch.device('cuda', local_rank)
     B = args.batch or B_PER_GPU
     lo = rank * B                                                      # global chain ids of this rank (weak scaling)
-    prob = build_problem(device, B, lo, deg=args.deg)
+    prob = build_problem(device, B, lo, deg=args.deg, tiny=args.tiny_score)
     eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device,
                                  chunk=args.chunk)
     x, p, y = prob['x'], prob['p'], prob['y']
@@ -459,7 +462,7 @@ def main():
         torch.cuda.synchronize()
         sharding.barrier()
         t0 = time.perf_counter()                                   # times the collective alone
-        allstats = sharding.gather_chains(stats.cpu() if args.rehearse_shared_gpu else stats, world * B, rank, world)
+        allstats = sharding.gather_chains(stats, world * B, rank, world)
         torch.cuda.synchronize()
         gather = dict(chains=int(allstats.shape[0]), ms=round(1e3 * (time.perf_counter() - t0), 3),
                       loss_mean=float(allstats[:, 0].double().mean()))
@@ -501,7 +504,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]' if args.deg == 'inpaint_random' else 'BASELINE configs[1] with another degradation') +
                                    f': FFHQ 256x256 {args.deg} sigma_0=0.05 tau=1.0 eps=0.05 '
-                                   f'timesteps=3, {B} chains per GPU, FFHQ U-Net architecture random-init fp32',
+                                   f'timesteps=3, {B} chains per GPU, ' +
+                                   ('REHEARSAL with a 32-channel U-Net (not the metric)' if args.tiny_score else 'FFHQ U-Net architecture random-init fp32'),
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
             'roofline': roofline, 'hot_path_only': hot, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,

@@ -124,7 +124,9 @@ int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_channels, c
 /* The same for a WHOLE-PIXEL mask (every pixel keeps all its channels or none, as main_sampling.py:290-305 builds them):
  * mask_words[hw/32] has bit (p % 32) of word p / 32 set when pixel p (row-major) is kept, prefix[hw/32] is the number of
  * kept pixels before each word, and y index = channels * rank(p) + channel.  Replaces the T-per-chain slot stream by
- * 16 KB of tables; hw % 32 == 0.  Same bits as nhmc_ddim_mix_bwd_inpaint. */
+ * 16 KB of tables; hw % 32 == 0.  Same bits as nhmc_ddim_mix_bwd_inpaint (g_xt, g_e; the loss to fp64 rounding).
+ * loss_ws: nhmc_inpaint_px_tiles(channels, hw) partials per chain (one per tile of a channel plane). */
+int nhmc_inpaint_px_tiles(int channels, int64_t hw);
 int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int e_channels, const float* at,
                                  const float* at_next, const float* y, const uint32_t* mask_words,
                                  const int32_t* prefix, int64_t m, float* g_xt, float* g_e, int fill_sigma,

@@ -24,6 +24,7 @@ SIGNATURES = {
     'nhmc_ddim_map_back': (I, [P, P, P, P, I, I64, P]),
     'nhmc_ddim_mix_bwd': (I, [P, P, P, P, P, I, P, P, I, P, P, I, I, I, I64, P]),
     'nhmc_ddim_mix_bwd_inpaint': (I, [P, P, I, P, P, P, P, I64, P, P, I, P, I, I, I64, P]),
+    'nhmc_inpaint_px_tiles': (I, [I, I64]),
     'nhmc_ddim_mix_bwd_inpaint_px': (I, [P, P, I, P, P, P, P, P, I64, P, P, I, P, I, I, I64, P]),
     'nhmc_ddim_mix_bwd_sr': (I, [P, P, I, P, P, P, I, P, P, P, I, I, I, P]),
     'nhmc_data_tiles': (I, [I64]),

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_data_inpaint(
   const int64_t base = (int64_t)chain * n4;
   const float* yb = y + (int64_t)chain * m;
   const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
-  float acc = 0.0f;
+  double acc = 0.0;                       // fp32 squares summed in fp64 (independent of the tiling; matches the fused forms)
   int4 sv[NHMC_VEC_PER_THREAD];
   float4 xv[NHMC_VEC_PER_THREAD];
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_data_inpaint(
       if (se[c] >= 0) {
         const float v = apply_clip ? nhmc_clip1(xe[c]) : xe[c];
         const float r = yb[se[c]] - v;
-        acc += r * r;
+        acc += (double)(r * r);
         gr = -(2.0f * r);
         if (apply_clip) gr = gr * nhmc_in1(xe[c]);
       }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_data_inpaint(
     nhmc_stnt(&g_xt[base + q], o);
   }
   __shared__ double red[4];
-  double v[1] = {(double)acc};
+  double v[1] = {acc};
   nhmc_block_sum<1>(v, red);
   if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
 }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
   const int64_t base = (int64_t)chain * n4, ebase = (int64_t)chain * e_stride4;
   const float* yb = y + (int64_t)chain * m;
   const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
-  float acc = 0.0f;
+  double acc = 0.0;                                          // fp32 squares summed in fp64: independent of the tiling
 #pragma unroll
   for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
       float gin = 0.0f;
       if (se[c] >= 0) {
         const float r = yb[se[c]] - nhmc_clip1(pre);
-        acc += r * r;
+        acc += (double)(r * r);
         gin = -(2.0f * r);
       }
       gin = gin * nhmc_in1(pre);                                 // final clip mask
@@ -218,9 +218,99 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint(
     }
   }
   __shared__ double red[4];
-  double v[1] = {(double)acc};
+  double v[1] = {acc};
   nhmc_block_sum<1>(v, red);
   if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
+}
+
+// Whole-pixel-mask form, restructured for latency (round 2; the form above reached 4.6 TB/s = 0.57 of the HBM peak with
+// no wasted traffic, i.e. it was latency / issue bound):
+//   * grid = (tiles of one channel plane, channel, chain): the channel and the pixel index come from the block index,
+//     no 64-bit division per float4;
+//   * every load that does not depend on data is issued up front, mask tables FIRST: hardware returns loads in issue
+//     order, so waiting for the (L2-resident, 16 KB) mask words leaves the 2 x VPT streaming loads of xt / e in flight;
+//   * the y gathers depend on the mask only, so they are issued next -- before any xt / e value is needed -- as
+//     predicated loads (8 % of the pixels are kept); the arithmetic then finds everything resident;
+//   * VPT float4 per thread of each stream (16-byte non-temporal accesses, 1 KiB contiguous per wave instruction).
+// Same arithmetic and bits as the form above (g_xt, g_e); loss partials: one per (tile, channel), fp64.
+template <int VPT>
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_inpaint_px(
+    const float4* __restrict__ xt, const float4* __restrict__ e, int64_t e_stride4, const float* __restrict__ at,
+    const float* __restrict__ at_next, const float* __restrict__ y, const uint32_t* __restrict__ mask_words,
+    const int32_t* __restrict__ prefix, int channels, int64_t hw4, int64_t m, float4* __restrict__ g_xt,
+    float4* __restrict__ g_e, double* __restrict__ loss_ws, int fill_sigma) {
+  const int chain = blockIdx.z, ch = blockIdx.y;
+  const Coef k = coef(at, at_next, chain);
+  const int64_t plane = ((int64_t)chain * channels + ch) * hw4;            // float4 offset of this channel plane
+  const int64_t eplane = (int64_t)chain * e_stride4 + (int64_t)ch * hw4;
+  const float* yb = y + (int64_t)chain * m + ch;                            // y index = channels * rank(pixel) + channel
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * VPT) + threadIdx.x;
+  uint32_t word[VPT];
+  int rank0[VPT];
+  float4 xv[VPT], ev[VPT];
+  bool ok[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    ok[i] = q < hw4;
+    word[i] = ok[i] ? mask_words[q >> 3] : 0u;                              // 8 float4 = 32 pixels per mask word
+    rank0[i] = ok[i] ? prefix[q >> 3] : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (ok[i]) { xv[i] = nhmc_ldnt(&xt[plane + q]); ev[i] = nhmc_ldnt(&e[eplane + q]); }
+  }
+  float yv[VPT][4];
+  unsigned kept[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    const int b0 = (int)(q & 7) * 4;
+    kept[i] = (word[i] >> b0) & 15u;
+    int rank = rank0[i] + __popc(word[i] & ((1u << b0) - 1u));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool kp = (kept[i] >> c) & 1u;
+      yv[i][c] = kp ? yb[(int64_t)rank * channels] : 0.0f;
+      rank += kp ? 1 : 0;
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    if (!ok[i]) continue;
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    const float* xe = reinterpret_cast<const float*>(&xv[i]);
+    const float* ee = reinterpret_cast<const float*>(&ev[i]);
+    float4 ox, oe;
+    float* gx = reinterpret_cast<float*>(&ox);
+    float* gee = reinterpret_cast<float*>(&oe);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float u = (xe[c] - ee[c] * k.c1) / k.c2;
+      const float pre = k.c3 * nhmc_clip1(u) + k.c4 * ee[c];    // decode before the final clip
+      float gin = 0.0f;
+      if ((kept[i] >> c) & 1u) {
+        const float r = yv[i][c] - nhmc_clip1(pre);
+        acc += (double)(r * r);
+        gin = -(2.0f * r);
+      }
+      gin = gin * nhmc_in1(pre);                                 // final clip mask
+      const float gu = ((gin * k.c3) * nhmc_in1(u)) / k.c2;
+      gx[c] = gu;
+      gee[c] = k.c4 * gin + (-gu) * k.c1;
+    }
+    nhmc_stnt(&g_xt[plane + q], ox);
+    nhmc_stnt(&g_e[eplane + q], oe);
+    // learned-sigma plane paired with this channel (e_channels = 2 C): zero-filled on request
+    if (fill_sigma && e_stride4 > (int64_t)channels * hw4)
+      nhmc_stnt(&g_e[eplane + (int64_t)channels * hw4 + q], make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  __shared__ double red[4];
+  double v[1] = {acc};
+  nhmc_block_sum<1>(v, red);
+  if (threadIdx.x == 0) loss_ws[((int64_t)chain * gridDim.y + ch) * gridDim.x + blockIdx.x] = v[0];
 }
 
 // Last DDIM step VJP fused with the super-resolution (r x r block mean) data term.  Work item = one float4 strip of
@@ -400,6 +490,13 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint(const float* xt, const float* e, int e_
   return nhmc_launch_status();
 }
 
+constexpr int PX_VPT = 1;       // float4 per thread and stream (tools/inpaint_bench.hip on MI355X, B = 64: 34.8 us at 1, 36.6 at 2, 38.2 at 4, 39.2 at 8; round-1 form 42.3)
+
+extern "C" int nhmc_inpaint_px_tiles(int channels, int64_t hw) {
+  const int64_t hw4 = hw / 4;
+  return (int)(channels * ((hw4 + NHMC_BLOCK * PX_VPT - 1) / (NHMC_BLOCK * PX_VPT)));
+}
+
 extern "C" int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int e_channels, const float* at,
                                             const float* at_next, const float* y, const uint32_t* mask_words,
                                             const int32_t* prefix, int64_t m, float* g_xt, float* g_e, int fill_sigma,
@@ -407,13 +504,13 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int
                                             nhmc_stream_t stream) {
   if (!xt || !e || !at || !at_next || !y || !mask_words || !prefix || !g_xt || !g_e || !loss_ws || m <= 0)
     return NHMC_ERR_ARG;
-  if (bad_shape(n_chains, channels, hw, e_channels) || (hw & 31)) return NHMC_ERR_SHAPE;
-  const int64_t n_elem = (int64_t)channels * hw;
+  if (bad_shape(n_chains, channels, hw, e_channels) || (hw & 31) || channels > 65535) return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e)) return NHMC_ERR_ALIGN;
-  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
-  NHMC_LAUNCH(k_mix_bwd_inpaint<true>, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,
-              (int64_t)e_channels * hw / 4, at, at_next, y, (const int4*)nullptr, mask_words, prefix, channels, hw, m,
-              (float4*)g_xt, (float4*)g_e, loss_ws, n_elem / 4, fill_sigma);
+  const int64_t hw4 = hw / 4;
+  dim3 grid((unsigned)((hw4 + NHMC_BLOCK * PX_VPT - 1) / (NHMC_BLOCK * PX_VPT)), (unsigned)channels, (unsigned)n_chains);
+  NHMC_LAUNCH(k_mix_bwd_inpaint_px<PX_VPT>, grid, dim3(NHMC_BLOCK), 0, nhmc_s(stream), (const float4*)xt,
+              (const float4*)e, (int64_t)e_channels * hw / 4, at, at_next, y, mask_words, prefix, channels, hw4, m,
+              (float4*)g_xt, (float4*)g_e, loss_ws, fill_sigma);
   return nhmc_launch_status();
 }
 

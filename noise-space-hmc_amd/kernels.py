@@ -99,6 +99,8 @@ def _mix_shapes(xt, e):
 
 
 def _alpha(a, B, device):
+    if a.dim() == 1 and a.numel() == B and a.dtype == torch.float32 and a.device == device and a.is_contiguous():
+        return a                                     # already the per-chain array the kernels take (engine's cached tables)
     a = a.reshape(-1)
     if a.numel() == 1 and B > 1:
         a = a.expand(B)
@@ -174,7 +176,7 @@ def ddim_mix_bwd_inpaint_px(xt, e, at, at_next, y, mask_words, prefix, g_e_out=N
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.empty_like(e)
-    tiles = leapfrog_tiles(Cc * hw)
+    tiles = lib.nhmc_inpaint_px_tiles(Cc, hw)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
     rc = lib.nhmc_ddim_mix_bwd_inpaint_px(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                           _p(y, torch.float32, 'y'), _p(mask_words, torch.int32, 'mask_words'),

@@ -113,6 +113,16 @@ class LeapfrogEngine:
         self.at = [table[idx[s, 0]].reshape(1).to(device) for s in range(len(steps))]
         self.at_next = [table[idx[s, 1]].reshape(1).to(device) for s in range(len(steps))]
         self.n_steps = len(steps)
+        self._per_n = {}                       # chunk size -> per-step (t, at, at_next) device arrays of that length
+
+    def _tables(self, n):
+        """Per-chain timestep / alpha-bar arrays for a chunk of n chains, built once per n (no per-step fill kernels)."""
+        hit = self._per_n.get(n)
+        if hit is None:
+            hit = self._per_n[n] = [(torch.full((n,), self.t_values[s], device=self.device),
+                                     self.at[s].expand(n).contiguous(), self.at_next[s].expand(n).contiguous())
+                                    for s in range(self.n_steps)]
+        return hit
 
     def _chunks(self, B):
         c = self.chunk or B
@@ -204,15 +214,15 @@ class LeapfrogEngine:
         batch-wide buffers) and returns the chunk's gradient pieces (g_direct, g_score or None)."""
         n = x.shape[0]
         S = self.n_steps
+        tab = self._tables(n)
         ins, outs = [], []
         cur = x
         for s in range(S):
             leaf = cur.detach().requires_grad_(True)
-            t = torch.full((n,), self.t_values[s], device=x.device)
             with torch.enable_grad():
-                e = self.score(leaf, t)
+                e = self.score(leaf, tab[s][0])
             e_c = e.detach() if e.is_contiguous() else e.detach().contiguous()
-            cur = K.ddim_mix_fwd(leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
+            cur = K.ddim_mix_fwd(leaf.detach(), e_c, tab[s][1], tab[s][2],
                                  final_clip=(s == S - 1), out=xt_out if s == S - 1 else None)['xt_next']
             ins.append((leaf, e_c))
             outs.append(e if e.requires_grad else None)           # None: score evaluated without gradient (latent model)
@@ -245,11 +255,10 @@ class LeapfrogEngine:
             leaf, e_c = ins[s]
             if fused and s == S - 1:                  # data term + last-step VJP in one kernel
                 extra = dict(xt_next=cur) if getattr(self.operator, 'fused_wants_decode', False) else {}
-                _, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, self.at[s].expand(n),
-                                                                self.at_next[s].expand(n), y, g_e_out=bufs[s],
-                                                                loss_out=loss_out, **extra)
+                _, g_direct, g_e = self.operator.fused_last_vjp(leaf.detach(), e_c, tab[s][1], tab[s][2], y,
+                                                                g_e_out=bufs[s], loss_out=loss_out, **extra)
             else:
-                g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, self.at[s].expand(n), self.at_next[s].expand(n),
+                g_direct, g_e = K.ddim_mix_bwd(g, leaf.detach(), e_c, tab[s][1], tab[s][2],
                                                final_clip=(s == S - 1), gout2=g2, want_g_e=outs[s] is not None,
                                                g_e_out=bufs[s] if outs[s] is not None else None)
             if outs[s] is not None:

@@ -2,9 +2,14 @@
 ROCm, xGMI between the GPUs of a node; "gloo" in the CPU tests).
 
 Chains are independent units (the score network has no cross-sample op; loss, Hamiltonian, accept and
-schedules are per chain), so the hot loop has NO collective.  Global chain i runs on rank
-i // ceil(B / W); its noise is keyed by i (PhiloxNoise), so the result does not depend on W.  The only
-exchange is one all_gather at the end: per-chain scalars (and, if asked, the collected samples).
+schedules are per chain), so the hot loop has NO collective.  Global chains are split into W contiguous
+blocks whose sizes differ by at most one (`chain_range`: the first B mod W ranks take one more); a chain's
+noise is keyed by its global id (PhiloxNoise) and, in the CLI, so are its measurement noise and start
+point, so the result does not depend on W.  The only exchange is one all_gather at the end: per-chain
+scalars (and, if asked, the collected samples).
+
+Rehearsal on a one-GPU box (tests): NHMC_DIST_BACKEND=gloo selects the backend and NHMC_SHARED_GPU=1 puts
+every rank on cuda:0; `gather_chains` then stages device tensors through the host for the collective.
 The reference has no multi-device path at all (`device_count` read and unused,
 main_sampling.py:369).
 """
@@ -16,13 +21,14 @@ import torch.distributed as dist
 
 def env_world():
     """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when not launched by it."""
-    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = 0 if os.environ.get('NHMC_SHARED_GPU') == '1' else int(os.environ.get('LOCAL_RANK', 0))
+    return int(os.environ.get('RANK', 0)), local, int(os.environ.get('WORLD_SIZE', 1))
 
 
 def init_process_group(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
-        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        backend = backend or os.environ.get('NHMC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         kw = {}
@@ -62,11 +68,14 @@ def gather_chains(local, n_chains, rank=None, world=None):
         return local
     sizes = [chain_range(n_chains, r, world) for r in range(world)]
     cap = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    via_host = local.is_cuda and dist.get_backend() == 'gloo'           # shared-GPU rehearsal: gloo moves host memory
+    src = local.cpu() if via_host else local
+    pad = torch.zeros((cap,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[: src.shape[0]] = src
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    out = torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    return out.to(local.device) if via_host else out
 
 
 def max_over_ranks(value, device):

@@ -161,11 +161,16 @@ def g3_ddim(ms, dim=32):
     save(f'g3_ddim_{dim}.npz', x=np32(x), w=np32(w), xt=np32(xt), grad=np32(grad))
 
 
-def g4_hmc(ms, deg, dim=32, seed=5678):
+def g4_hmc(ms, deg, dim=32, seed=5678, f64=False):
+    """f64=True -> g14_hmc_f64_*: the same reference run with the tiny score evaluated in float64 (oracle.tiny_score.F64Score,
+    the model is hmc()'s argument); stores every uniform and -dH so a GPU test can replay the whole run on the same tape."""
     from algos.unconditional import Unconditional
     ops, missing = build_ops(ms, dim, seed=900 + dim)
     Hf = ops[deg]
     net = tiny_model()
+    if f64:
+        from oracle.tiny_score import F64Score
+        net = F64Score(net)
     b = torch.from_numpy(ms.get_beta_schedule(beta_schedule='linear', beta_start=1e-4, beta_end=0.02,
                                               num_diffusion_timesteps=1000)).float()
     g = torch.Generator().manual_seed(11)
@@ -187,6 +192,7 @@ def g4_hmc(ms, deg, dim=32, seed=5678):
         out = real_randn_like(*a, **k)
         if len(rec['p']) < 1:
             rec['p'].append(out.clone())
+        rec['p_last'] = [out.clone()]
         return out
 
     def rand(*a, **k):
@@ -224,7 +230,11 @@ def g4_hmc(ms, deg, dim=32, seed=5678):
     if deg == 'aniso':
         for k, v in export_aniso(Hf).items():
             arrays[f'aniso_{k}'] = v
-    save(f'g4_hmc_{deg}_{dim}.npz', **arrays)
+    if f64:
+        for k in ('pos_first', 'pos_last', 'dec_last', 'dec_init'):
+            arrays.pop(k)
+        arrays['p_last'] = np32(rec['p_last'][0])
+    save(f'g14_hmc_f64_{deg}_{dim}.npz' if f64 else f'g4_hmc_{deg}_{dim}.npz', **arrays)
     print(f'   {deg}: {len(rec["u"])} iterations, {len(psnr)} accepts, final PSNR {psnr[-1]:.3f}')
 
 
@@ -270,6 +280,13 @@ def g13_aniso_256(ms):
     assert int(ex['perm'].max()) < 65536
     save('g13_aniso_256.npz', **arrays)
 
+
+if __name__ == '__main__' and 'g14' in sys.argv[1:]:
+    _ms = import_reference()
+    torch.set_num_threads(4)
+    for _deg in ('inpaint', 'sr4', 'aniso'):
+        g4_hmc(_ms, _deg, f64=True)
+    sys.exit(0)
 
 if __name__ == '__main__' and 'g13' in sys.argv[1:]:
     g13_aniso_256(import_reference())

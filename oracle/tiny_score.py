@@ -36,3 +36,18 @@ def make_tiny_score(seed=1234):
         for prm in net.parameters():
             prm.copy_(torch.randn(prm.shape, generator=g) * (0.35 / math.sqrt(max(1, prm[0].numel()))))
     return net.eval().requires_grad_(False)
+
+
+class F64Score(nn.Module):
+    """A score network evaluated in float64 and rounded to float32 (inputs / outputs stay fp32): CPU (oneDNN) and GPU
+    convolutions then agree to ~1e-15 before the rounding, so a many-trajectory comparison is sensitive to the sampler's
+    kernels and not to the amplification of conv-implementation noise.  The model is an ARGUMENT of the reference's
+    `hmc()`, so wrapping it leaves the reference code untouched (fixtures G14)."""
+
+    def __init__(self, net):
+        super().__init__()
+        import copy
+        self.net = copy.deepcopy(net).double()
+
+    def forward(self, x, t):
+        return self.net(x.double(), t.double()).float()

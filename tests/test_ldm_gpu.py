@@ -219,3 +219,33 @@ def test_ffhq_width_latent_model_runs_one_trajectory():
     assert bool(torch.isfinite(got['H1']).all()) and bool(torch.isfinite(got['xt']).all()) and not torch.equal(got['x_prop'], x)
     img = model.decode_first_stage(got['xt'])
     assert img.shape == (2, 3, 256, 256)
+
+
+def test_latent_cli_runs_the_reference_command_line(tmp_path, monkeypatch, capsys):
+    """`main_sampling_latent.py`-compatible flags end to end (main_sampling_latent.py:791-918) on a small latent config
+    written in the reference's yaml layout (configs/config_ffhq_latent.yml: target / params nesting)."""
+    import yaml
+    from nhmc import cli
+    cfg = {'data': {'dataset': 'tiny', 'image_size': 64, 'channels': 3, 'rescaled': True},
+           'model_type': 'ffhq_latent',
+           'model': {'target': 'ldm.models.diffusion.ddpm.LatentDiffusion',
+                     'params': {'linear_start': 0.0015, 'linear_end': 0.0195, 'timesteps': 1000, 'image_size': 16, 'channels': 3,
+                                'first_stage_key': 'image', 'cond_stage_config': '__is_unconditional__',
+                                'unet_config': {'target': 'ldm.modules.diffusionmodules.openaimodel.UNetModel', 'params': UNET_SMALL},
+                                'first_stage_config': {'target': 'ldm.models.autoencoder.VQModelInterface',
+                                                       'params': {'embed_dim': 3, 'n_embed': 256, 'ckpt_path': 'models/first_stage_models/vq-f4/model.ckpt',
+                                                                  'ddconfig': DEC_SMALL, 'lossconfig': {'target': 'torch.nn.Identity'}}}}}}
+    (tmp_path / 'configs').mkdir()
+    (tmp_path / 'configs' / 'config_tiny_latent.yml').write_text(yaml.safe_dump(cfg))
+    monkeypatch.chdir(tmp_path)
+    opt = cli.get_parser(latent=True).parse_known_args(['--deg', 'sr4', '--sigma_0', '0.05'])[0]
+    assert opt.epsilon == 0.1 and opt.sigma_y == 0.5 and not hasattr(opt, 'annealed_temp')      # the latent entry's defaults
+    table = cli.main_latent(['--dataset', 'tiny', '--algo', 'hmc_latent', '--timesteps', '3', '--deg', 'inpaint_random', '--sigma_0', '0.05',
+                             '-i', str(tmp_path / 'out'), '--tau', '0.1', '--epsilon', '0.1', '--sigma_y', '1.0', '--synthetic', '2',
+                             '--chains', '2', '--philox'])
+    assert table.shape == (2, 3) and table[:, 0].tolist() == [0.0, 1.0]
+    assert 'Total Average PSNR' in capsys.readouterr().out
+    with pytest.raises(NotImplementedError):
+        cli.main_latent(['--dataset', 'tiny', '--algo', 'hmc', '--deg', 'sr4', '--sigma_0', '0.05'])
+    with pytest.raises(NotImplementedError):
+        cli.main(['--dataset', 'tiny', '--algo', 'hmc_latent', '--deg', 'sr4', '--sigma_0', '0.05'])

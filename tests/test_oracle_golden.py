@@ -156,3 +156,18 @@ def test_g5_operators_256(golden):
         assert rel(hx[0, T(g[f'{name}_probe_m'])].numpy(), g[f'{name}_Hx_probe']) <= tol
         assert rel(hty[0, T(g[f'{name}_probe_n'])].numpy(), g[f'{name}_Hty_probe']) <= tol
         assert abs(float(hx.double().norm()) / float(g[f'{name}_Hx_norm']) - 1) < 1e-6
+
+
+def test_g14_oracle_reproduces_the_reference_run_with_the_f64_score(golden, tiny_score):
+    """G14 = the reference's `hmc()` with the tiny score evaluated in float64 (the tape the GPU whole-run test replays):
+    the oracle reproduces it bit for bit too."""
+    from oracle.tiny_score import F64Score
+    g = golden('g14_hmc_f64_sr4_32.npz')
+    torch.manual_seed(int(g['seed']))
+    trace = {}
+    out = hmc_ref.hmc_reference(T(g['x']), schedule.betas_fp32(), SEQ, SEQ_NEXT, F64Score(tiny_score), operators.BlockMeanRef(3, 32, 4),
+                                T(g['y_0']), T(g['x_orig']), tau=float(g['tau']), epsilon=float(g['epsilon']),
+                                m=float(g['m']), sigma_0=float(g['sigma_0']), trace=trace)
+    assert len(trace['accept']) == len(g['u']) and sum(trace['accept']) == 100
+    assert np.allclose(-np.array(trace['dH']), g['neg_dH'], rtol=0, atol=0.05)
+    assert rel(out.numpy(), g['out']) <= 2e-5
