@@ -270,7 +270,7 @@ def cpu_baseline(seed=5678):
                 sample=f'oracle (oracle/hmc_ref.py) leapfrog steps, B=1, {steps} consecutive steps, FFHQ U-Net fp32 on CPU: {dt:.1f} s',
                 score_stubbed=dict(b1_chain_steps_per_s=round(n1 / s1, 1), b1_ms_per_step=round(1e3 * s1 / n1, 2),
                                    b64_chain_steps_per_s=round(64 * n64 / s64, 1), b64_ms_per_step=round(1e3 * s64 / n64, 1),
-                                   sample=f'same oracle step with a two-op stand-in score: {n1} steps at B=1 ({s1:.1f} s), '
+                                   sample=f'same oracle step with a two-op stand-in score: {n1} steps at B=1 ({s1:.2f} s), '
                                           f'{n64} steps at B=64 ({s64:.1f} s); compare with hot_path_only'))
 
 
@@ -320,6 +320,10 @@ def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding
         step()
     sharding.barrier()
     torch.cuda.synchronize()
+    mark = torch.zeros(2, 4, device=device) if os.environ.get('NHMC_PROFILE_MARK') == '1' else None
+    if mark is not None:                       # one-block marker dispatches bracketing the timed region in a rocprofv3
+        K.copy_probe(mark[0], mark[1])         # kernel trace (profiles/summarize.py keeps the steady-state rows between them)
+        torch.cuda.synchronize()
     eng.update_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -327,6 +331,9 @@ def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding
     torch.cuda.synchronize()
     sharding.barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, device)
+    if mark is not None:
+        K.copy_probe(mark[0], mark[1])
+        torch.cuda.synchronize()
     events, eng.update_events = eng.update_events, None
     return dt, loss.clone(), events
 

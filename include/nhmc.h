@@ -349,6 +349,23 @@ int nhmc_schedule_begin_mass(const int32_t* epoch, double* tau, double* eps, dou
 int nhmc_vq_nearest(const float* z, const float* codebook, float* z_q, int32_t* idx, int n_chains,
                     int channels, int64_t hw, int n_embed, nhmc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * a16 glue  Fused GroupNorm (+ FiLM scale/shift) (+ SiLU) of the score networks, forward and input gradient
+ *      guided_diffusion/unet_ffhq.py:310-321 (GroupNorm32, scale-shift norm, SiLU); ldm/modules/diffusionmodules/model.py:38-39
+ *   u = ((x - mean_g) rstd_g gamma_c + beta_c) (1 + scale_bc) + shift_bc ;   y = act ? u sigmoid(u) : u
+ * x, y, dy, dx: [n][channels][hw] contiguous fp32 (hw % 4 == 0); gamma, beta: [channels];
+ * film (nullable): [n][film_stride] with scale at [c] and shift at [channels + c] (the reference's emb_out.chunk(2)).
+ * ws: double[n * groups][splits][2] partial sums (splits = nhmc_gn_splits(...)); the forward's ws is an input of the
+ * backward (mean / rstd are re-derived from it; nothing else is saved).  Only dx is produced: the networks are frozen.
+ * ---------------------------------------------------------------------------------- */
+int nhmc_gn_splits(int n, int channels, int groups, int64_t hw);
+int nhmc_gn_act_fwd(const float* x, const float* gamma, const float* beta, const float* film, int64_t film_stride,
+                    float eps, int act, float* y, double* ws, int splits, int n, int channels, int groups,
+                    int64_t hw, nhmc_stream_t stream);
+int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* film,
+                    int64_t film_stride, float eps, int act, const double* fwd_ws, float* dx, double* ws,
+                    int splits, int n, int channels, int groups, int64_t hw, nhmc_stream_t stream);
+
 /* PSNR of clamp((xt+1)/2,0,1) against clamp((x_orig+1)/2,0,1)   main_sampling.py:738-739
  * ws: double[n_chains][nhmc_data_tiles(n_elem)]. */
 int nhmc_psnr(const float* xt, const float* x_orig, float* psnr, double* ws,

@@ -21,6 +21,7 @@
 // wave), K step 32, synchronous global->LDS staging (latency covered by the other resident blocks).  Epilogues fuse the spectral multiplier, the residual + per-tile loss partial, and the
 // -2 * clip-mask scaling; PRECLIP clamps IN on the fly (the data term's final clip).
 #include "nhmc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -188,6 +189,206 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
   }
 }
 
+// ---- two products per launch (d = 256): OUT = (IN^T S1)^T S2, the intermediate never leaves the CU --------------------
+// Round 2.  The chain above moves every intermediate through HBM (8 launches, ~16T of intermediates per chain against 3T
+// algorithmic) and, because all 768 blocks of a product are co-resident and in lock-step, its store epilogues and first
+// loads are never overlapped with another block's MFMAs.  Here one block owns a 64-column slab of the intermediate
+//     T1[:, slab] = IN^T S1[:, slab]      (256 x 64 fp32 = 64 KB, kept in LDS)
+// and immediately consumes it as the k-major left operand of the second product
+//     OUT[slab rows][:] = T1[:, slab]^T S2 (64 x 256),
+// so a pair of products costs one launch, one prologue and one epilogue, and T1 is never written.  4 blocks per image
+// (768 per pair at B = 64 = 3 per CU, one resident at a time: 128 KB of LDS), 8 waves per block = two per SIMD.
+// The main loops have NO block barrier: the operand every wave shares is resident in LDS for the whole phase (the S1
+// slab in phase 1, staged once; the T1 slab in phase 2), and the operand a wave needs alone (its 32 rows of IN, its 32
+// columns of S2) is read straight from global / L2 into MFMA fragments, 16 k-pairs ahead in registers, so waves drift
+// freely and the two waves of a SIMD fill each other's latencies.  MFMA count, k order and epilogues are those of the
+// two-launch form: the same bits.  Measured at B = 64 (data term + last VJP, tools/pair_bench.py): one product per
+// launch 525 us; this form 522 us (98.7 TFLOP/s); with per-K-step LDS staging of both operands + a block barrier 562 us
+// (8 waves) / 643 us (4 waves); with the S1 slab read from global instead of LDS (64 KB, two blocks per CU) 676 us.
+// So the pair form does not beat the chain on time -- each block still serialises ~16 us of slab staging, barriers and
+// the 64 KB epilogue against 27 us of MFMA work, and one block fits a CU -- but it halves the launches and keeps
+// half of the intermediates (8T of 16T per chain) out of HBM.
+template <int EPI, bool PRECLIP>
+__global__ __launch_bounds__(512, 1) void k_pair256(
+    const float* __restrict__ IN, const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ OUT,
+    const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int channels, VjpArgs vj) {
+  constexpr int D = 256, SL = 64, NW = 8, NT = 64 * NW, CHK = 16;       // CHK: k-pairs fetched ahead per register set
+  extern __shared__ float lds[];
+  float* const slab = lds;                                  // [256][64]  T1[k'][r'], later the epilogue's [64][256] staging
+  float* const s1s = lds + D * SL;                          // [256][64]  S1[k][slab columns]
+  const int total = gridDim.x;
+  int logical = blockIdx.x;
+  if ((total & 7) == 0) logical = (logical & 7) * (total >> 3) + (logical >> 3);   // the 4 slabs of an image share an XCD
+  const int img = logical >> 2, q = logical & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const float* __restrict__ Ximg = IN + (int64_t)img * D * D;
+
+#pragma unroll
+  for (int v = 0; v < D * SL / 4 / NT; ++v) {               // S1[:, slab] -> LDS, once
+    const int idx = tid + v * NT, kk = idx / (SL / 4), c4 = idx % (SL / 4);
+    *reinterpret_cast<nhmc_v4f*>(&s1s[kk * SL + c4 * 4]) = *reinterpret_cast<const nhmc_v4f*>(&S1[(int64_t)kk * D + q * SL + c4 * 4]);
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+
+  // ------------------------------------------------ phase 1: T1[32 wave rows][slab] = IN^T S1[:, slab] ---------------
+  {
+    const float* __restrict__ ap = Ximg + wave * 32 + lr + (int64_t)lh * D;     // a(k-pair j) = ap[2 j D]: IN[2j + lh][row]
+    float f0[CHK], f1[CHK];
+    auto fetch = [&](float (&fa)[CHK], int c) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) fa[j] = ap[(int64_t)(2 * (c + j)) * D];
+    };
+    auto compute = [&](const float (&fa)[CHK], int c) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) {
+        const int kk = 2 * (c + j);
+        const float a = PRECLIP ? nhmc_clip1(fa[j]) : fa[j];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s1s[(kk + lh) * SL + lr], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s1s[(kk + lh) * SL + 32 + lr], acc[1], 0, 0, 0);
+      }
+    };
+    fetch(f0, 0);
+    __syncthreads();                                        // S1 slab resident
+    for (int c0 = 0; c0 < D / 2; c0 += 2 * CHK) {
+      fetch(f1, c0 + CHK);
+      compute(f0, c0);
+      if (c0 + 2 * CHK < D / 2) fetch(f0, c0 + 2 * CHK);
+      compute(f1, c0 + CHK);
+    }
+  }
+  // accumulators -> slab[k' = row of T1][r' = slab column]   (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 lh)
+#pragma unroll
+  for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      slab[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SL + fb * 32 + lr] = acc[fb][r];
+      acc[fb][r] = 0.0f;
+    }
+
+  // ------------------------------------------------ phase 2: OUT[slab][32 wave columns] = T1[:, slab]^T S2 -----------
+  {
+    const float* __restrict__ bp = S2 + wave * 32 + lr + (int64_t)lh * D;       // b(k-pair j) = bp[2 j D]: S2[2j + lh][col]
+    float f0[CHK], f1[CHK];
+#pragma unroll
+    for (int j = 0; j < CHK; ++j) f0[j] = bp[(int64_t)(2 * j) * D];
+    __syncthreads();                                        // T1 slab complete
+    for (int c0 = 0; c0 < D / 2; c0 += 2 * CHK) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) f1[j] = bp[(int64_t)(2 * (c0 + CHK + j)) * D];
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) {
+        const int kk = 2 * (c0 + j);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + lr], f0[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + 32 + lr], f0[j], acc[1], 0, 0, 0);
+      }
+      if (c0 + 2 * CHK < D / 2) {
+#pragma unroll
+        for (int j = 0; j < CHK; ++j) f0[j] = bp[(int64_t)(2 * (c0 + 2 * CHK + j)) * D];
+      }
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) {
+        const int kk = 2 * (c0 + CHK + j);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + lr], f1[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + 32 + lr], f1[j], acc[1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ------------------------------------------------ epilogue: [64 rows][256 cols] through the slab's 64 KB -----------
+  __syncthreads();                                          // every wave is done reading the T1 slab
+#pragma unroll
+  for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      slab[(fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * 32 + lr] = acc[fa][r];
+  __syncthreads();
+  const int c = img % channels;
+  float* __restrict__ out_img = OUT + (int64_t)img * D * D;
+  const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * D * D : nullptr;
+  const float* __restrict__ aux_img = aux ? aux + (int64_t)img * D * D : nullptr;
+  const float* __restrict__ e_img = nullptr;
+  float* __restrict__ ge_img = nullptr;
+  float c1 = 0.f, c2 = 1.f, c3 = 0.f, c4 = 0.f;
+  if (EPI == EPI_VJP) {
+    const int chain = img / channels;
+    const int64_t eoff = ((int64_t)chain * vj.e_channels + c) * D * D;
+    e_img = vj.e + eoff;
+    ge_img = vj.g_e + eoff;
+    const float a = vj.at[chain], an = vj.at_next[chain];
+    c1 = sqrtf(1.0f - a); c2 = sqrtf(a); c3 = sqrtf(an); c4 = sqrtf(1.0f - an);
+  }
+  float lsum = 0.0f;
+#pragma unroll 4
+  for (int v = 0; v < SL * D / 4 / NT; ++v) {
+    const int idx = tid + v * NT, row = idx / (D / 4), c4i = idx % (D / 4);
+    const int off = (q * SL + row) * D + c4i * 4;
+    nhmc_v4f o = *reinterpret_cast<const nhmc_v4f*>(&slab[row * D + c4i * 4]);
+    if (EPI == EPI_MULD) o = o * *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
+    if (EPI == EPI_RESID) {
+      o = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]) - o;                   // r = y - H x
+      lsum += o.x * o.x; lsum += o.y * o.y; lsum += o.z * o.z; lsum += o.w * o.w;
+    }
+    if (EPI == EPI_GRAD) {
+      o = -(2.0f * o);
+      if (aux_img) {
+        const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+        o.x = o.x * nhmc_in1(xv.x); o.y = o.y * nhmc_in1(xv.y); o.z = o.z * nhmc_in1(xv.z); o.w = o.w * nhmc_in1(xv.w);
+      }
+    }
+    if (EPI == EPI_VJP) {                                   // same op order as k_mix_bwd<false,false>, final_clip = 1
+      const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+      const nhmc_v4f ev = *reinterpret_cast<const nhmc_v4f*>(&e_img[off]);
+      nhmc_v4f ge;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const float ee = ev[k4];
+        const float u = (xv[k4] - ee * c1) / c2;
+        float gin = -(2.0f * o[k4]);
+        gin = gin * nhmc_in1(c3 * nhmc_clip1(u) + c4 * ee);
+        const float gu = ((gin * c3) * nhmc_in1(u)) / c2;
+        ge[k4] = c4 * gin + (-gu) * c1;
+        o[k4] = gu;
+      }
+      *reinterpret_cast<nhmc_v4f*>(&ge_img[off]) = ge;
+    }
+    *reinterpret_cast<nhmc_v4f*>(&out_img[off]) = o;
+  }
+  if (EPI == EPI_RESID) {
+    __shared__ double red[NW];
+    double sw = nhmc_wave_sum((double)lsum);
+    if (lane == 0) red[wave] = sw;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < NW; ++w) tot += red[w];
+      ws[(int64_t)img * 4 + q] = tot;
+    }
+  }
+}
+
+constexpr int PAIR_LDS_BYTES = 2 * 256 * 64 * 4;            // T1 slab + S1 slab = 128 KB
+
+template <int EPI, bool PRECLIP>
+int pair256(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
+            int n_img, int channels, hipStream_t st, VjpArgs vj = VjpArgs{}) {
+  static bool attr_set[64] = {};                             // raise the dynamic-LDS limit of this instantiation once per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair256<EPI, PRECLIP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES) != hipSuccess)
+      return NHMC_ERR_LAUNCH;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  NHMC_LAUNCH((k_pair256<EPI, PRECLIP>), dim3((unsigned)(4 * n_img)), dim3(512), PAIR_LDS_BYTES, st, IN, S1, S2, OUT, Dmap, aux,
+              ws, channels, vj);
+  return nhmc_launch_status();
+}
+
 int tile_of2(int R, int C) { return (R % 128 == 0 && C % 128 == 0) ? 128 : ((R % 64 == 0 && C % 64 == 0) ? 64 : 32); }
 
 // OUT[R][C] = IN[K][R]^T * S[K][C] per image; K % 32 == 0, R % 32 == 0, C % 32 == 0.
@@ -213,6 +414,12 @@ int gemm(const float* IN, const float* S, float* OUT, const float* Dmap, const f
 
 int tile_of(int d) { return d % 128 == 0 ? 128 : (d % 64 == 0 ? 64 : 32); }
 
+// A/B switch for tools/pair_bench.hip and the parity tests: NHMC_SPECTRAL_PAIRS=0 keeps the one-product-per-launch chain.
+bool pairs_enabled() {
+  const char* v = getenv("NHMC_SPECTRAL_PAIRS");
+  return !(v && v[0] == '0');
+}
+
 bool bad(int n_chains, int channels, int dim) {
   return n_chains <= 0 || channels <= 0 || dim <= 0 || (dim % 32) || (int64_t)n_chains * channels > 65535;
 }
@@ -237,6 +444,10 @@ extern "C" int nhmc_spectral_apply(const float* x, const float* L, const float* 
   hipStream_t st = nhmc_s(stream);
   const int n = n_chains * channels;
   int rc;
+  if (dim == 256 && pairs_enabled()) {
+    if ((rc = pair256<EPI_MULD, false>(x, L, R, tmp, Dmap, nullptr, nullptr, n, channels, st))) return rc;      // (L^T X R) o D
+    return pair256<EPI_NONE, false>(tmp, LoT, RoT, out, nullptr, nullptr, nullptr, n, channels, st);              // Lo . Ro^T
+  }
   if ((rc = gemm<EPI_NONE, false>(x, L, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;     // X^T L
   if ((rc = gemm<EPI_MULD, false>(tmp, R, out, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;       // (L^T X R) o D
   if ((rc = gemm<EPI_NONE, false>(out, LoT, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;  // (Lo .)^T
@@ -261,6 +472,13 @@ extern "C" int nhmc_data_spectral(const float* xt, const float* y, const float* 
   float* A = tmp;
   float* B = tmp + (int64_t)n * dd;
   int rc;
+  if (dim == 256 && pairs_enabled()) {                      // two products per launch, intermediates stay in LDS
+    if (apply_clip) { if ((rc = pair256<EPI_MULD, true>(xt, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc; }
+    else            { if ((rc = pair256<EPI_MULD, false>(xt, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc; }
+    if ((rc = pair256<EPI_RESID, false>(A, U1T, U2T, B, nullptr, y, loss_ws, n, channels, st))) return rc;
+    if ((rc = pair256<EPI_MULD, false>(B, U1, U2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;
+    return pair256<EPI_GRAD, false>(A, V1T, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, st);
+  }
   // r = y - U1 (D o (V1^T clip(xt) V2)) U2^T
   if (apply_clip) { if ((rc = gemm<EPI_NONE, true>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
   else            { if ((rc = gemm<EPI_NONE, false>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
@@ -294,6 +512,13 @@ extern "C" int nhmc_data_spectral_vjp(const float* xt_next, const float* y, cons
   float* A = tmp;
   float* B = tmp + (int64_t)n * dd;
   int rc;
+  if (dim == 256 && pairs_enabled()) {
+    const VjpArgs vjp{e, g_e, at, at_next, e_channels};
+    if ((rc = pair256<EPI_MULD, false>(xt_next, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;
+    if ((rc = pair256<EPI_RESID, false>(A, U1T, U2T, B, nullptr, y, loss_ws, n, channels, st))) return rc;
+    if ((rc = pair256<EPI_MULD, false>(B, U1, U2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;
+    return pair256<EPI_VJP, false>(A, V1T, V2T, g_xt, nullptr, xt, nullptr, n, channels, st, vjp);
+  }
   if ((rc = gemm<EPI_NONE, false>(xt_next, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
   if ((rc = gemm<EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
   if ((rc = gemm<EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;

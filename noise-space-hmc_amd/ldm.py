@@ -32,7 +32,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import kernels as K
-from .unet import AttentionBlock, Stage, sinusoid, sinusoid_freqs
+from .unet import AttentionBlock, Stage, group_norm_act, sinusoid, sinusoid_freqs
 
 # configs/config_ffhq_latent.yml:45-80
 FFHQ_LDM_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=(8, 4, 2),
@@ -81,8 +81,8 @@ class AddEmbResBlock(nn.Module):
         self.skip_connection = nn.Identity() if out_ch == ch else nn.Conv2d(ch, out_ch, 1)
 
     def forward(self, x, emb):
-        h = self.in_layers(x) + self.emb_layers(emb)[:, :, None, None]
-        return self.skip_connection(x) + self.out_layers(h)
+        h = self.in_layers[2](group_norm_act(self.in_layers[0], x)) + self.emb_layers(emb)[:, :, None, None]
+        return self.skip_connection(x) + self.out_layers[3](group_norm_act(self.out_layers[0], h))
 
 
 class LDMUNet(nn.Module):
@@ -144,7 +144,7 @@ class LDMUNet(nn.Module):
         h = self.middle_block(h, emb)
         for blk in self.output_blocks:
             h = blk(torch.cat([h, hs.pop()], dim=1), emb)
-        return self.out(h)
+        return self.out[2](group_norm_act(self.out[0], h))
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -169,8 +169,8 @@ class PlainResBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
-        h = self.conv1(_swish(self.norm1(x)))
-        h = self.conv2(_swish(self.norm2(h)))
+        h = self.conv1(group_norm_act(self.norm1, x, act_fn=_swish))     # Normalize + x sigmoid(x)
+        h = self.conv2(group_norm_act(self.norm2, h, act_fn=_swish))
         return (self.nin_shortcut(x) if hasattr(self, 'nin_shortcut') else x) + h
 
 
@@ -183,7 +183,7 @@ class SpatialSelfAttention(nn.Module):
         self.q, self.k, self.v, self.proj_out = (nn.Conv2d(ch, ch, 1) for _ in range(4))
 
     def forward(self, x):
-        h = self.norm(x)
+        h = group_norm_act(self.norm, x, act=False)
         b, c, hh, ww = x.shape
         q, k, v = (f(h).reshape(b, c, hh * ww) for f in (self.q, self.k, self.v))
         w = torch.softmax(torch.bmm(q.permute(0, 2, 1), k) * (int(c) ** (-0.5)), dim=2)
@@ -252,7 +252,7 @@ class VQDecoder(nn.Module):
                     h = lvl.attn[i_block](h)
             if i_level != 0:
                 h = lvl.upsample(h)
-        return self.conv_out(_swish(self.norm_out(h)))
+        return self.conv_out(group_norm_act(self.norm_out, h, act_fn=_swish))
 
 
 class _StraightThroughVQ(torch.autograd.Function):

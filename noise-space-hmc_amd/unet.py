@@ -10,10 +10,13 @@ configs/config_ffhq.yml:17-35).  When the checkpoint is absent the weights stay 
 as in the reference's own fallback (unet_ffhq.py:87-90).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import kernels as K
 
 FFHQ_CONFIG = dict(image_size=256, num_channels=128, num_res_blocks=1, channel_mult='', learn_sigma=True,
                    attention_resolutions='16', num_head_channels=64, use_scale_shift_norm=True,
@@ -32,6 +35,46 @@ def sinusoid(t, dim, freqs=None):
     ang = t[:, None].float() * freqs[None]
     emb = torch.cat([ang.cos(), ang.sin()], dim=-1)
     return F.pad(emb, (0, dim % 2))
+
+
+class _GroupNormAct(torch.autograd.Function):
+    """y = act(GroupNorm(x) (1 + scale) + shift) on the fused HIP kernels (csrc/gn_act.hip): 2 reads + 1 write forward,
+    4 reads + 1 write for the input gradient, nothing but x saved -- against 5R + 4W / 7R + 3W for the ATen op sequence
+    the reference's GroupNorm32 + scale-shift + SiLU lowers to (unet_ffhq.py:310-321)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, groups, eps, act):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y, ws, splits = K.gn_act_fwd(xc, gamma, beta, groups, eps, act, film)
+        ctx.save_for_backward(xc, gamma, beta, ws, *([film] if film is not None else []))
+        ctx.meta = (groups, eps, act, splits)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gamma, beta, ws, *rest = ctx.saved_tensors
+        groups, eps, act, splits = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = K.gn_act_bwd(xc, dy, gamma, beta, groups, eps, act, rest[0] if rest else None, ws, splits)
+        return dx, None, None, None, None, None, None
+
+
+def group_norm_act(gn, x, act=True, film=None, act_fn=F.silu):
+    """GroupNorm `gn` (+ FiLM terms `film` = [B, 2C] scale | shift) (+ SiLU) of a score network.
+
+    fp32 GPU tensors with frozen parameters -- the sampler's case -- run the fused HIP kernels (NHMC_FUSED_GN=0 keeps
+    the ATen sequence for A/B measurements); anything else (CPU tensors of the fixtures' side, float64 evaluation in the
+    parity tests, parameters that require grad) is plain torch, as for any other module of this file -- with `act_fn`
+    the activation in the reference's own form (nn.SiLU in the ADM U-Nets, x * sigmoid(x) in the VQ decoder)."""
+    hw = x[0, 0].numel()
+    if x.is_cuda and x.dtype == torch.float32 and hw % 4 == 0 and not (gn.weight.requires_grad or gn.bias.requires_grad) \
+            and (film is None or not film.requires_grad) and os.environ.get('NHMC_FUSED_GN', '1') != '0':
+        return _GroupNormAct.apply(x, gn.weight, gn.bias, film, gn.num_groups, gn.eps, act)
+    h = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
+    if film is not None:
+        scale, shift = film.reshape(film.shape + (1,) * (x.dim() - 2)).chunk(2, dim=1)
+        h = h * (1 + scale) + shift
+    return act_fn(h) if act else h
 
 
 class Resample(nn.Module):
@@ -60,15 +103,12 @@ class ResBlock(nn.Module):
         self.skip_connection = nn.Identity() if out_ch == ch else nn.Conv2d(ch, out_ch, 1)
 
     def forward(self, x, emb):
+        h = group_norm_act(self.in_layers[0], x)                         # GroupNorm + SiLU
         if self.resample:
-            h = self.in_layers[1](self.in_layers[0](x))
             h, x = self.h_upd(h), self.x_upd(x)
-            h = self.in_layers[2](h)
-        else:
-            h = self.in_layers(x)
-        scale, shift = self.emb_layers(emb)[:, :, None, None].chunk(2, dim=1)
-        h = self.out_layers[0](h) * (1 + scale) + shift                  # scale-shift norm (FiLM)
-        h = self.out_layers[3](self.out_layers[1](h))
+        h = self.in_layers[2](h)
+        h = group_norm_act(self.out_layers[0], h, film=self.emb_layers(emb))   # scale-shift norm (FiLM) + SiLU
+        h = self.out_layers[3](h)
         return self.skip_connection(x) + h
 
 
@@ -85,7 +125,7 @@ class AttentionBlock(nn.Module):
     def forward(self, x):
         b, c, hh, ww = x.shape
         x = x.reshape(b, c, -1)
-        qkv = self.qkv(self.norm(x))
+        qkv = self.qkv(group_norm_act(self.norm, x, act=False))
         # "legacy" order: heads are split before q/k/v
         q, k, v = qkv.reshape(b * self.heads, 3 * c // self.heads, -1).split(c // self.heads, dim=1)
         s = 1 / math.sqrt(math.sqrt(c // self.heads))
@@ -149,7 +189,7 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb)
         for blk in self.output_blocks:
             h = blk(torch.cat([h, hs.pop()], dim=1), emb)
-        return self.out(h)
+        return self.out[2](group_norm_act(self.out[0], h))
 
 
 def create_model(image_size=256, num_channels=128, num_res_blocks=1, channel_mult='', learn_sigma=True,

@@ -20,7 +20,7 @@ from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-OURS = ('k_leapfrog', 'k_mix_', 'k_map_back', 'k_data_inpaint', 'k_inpaint', 'k_sr', 'k_sgemm', 'k_sum_partials',
+OURS = ('k_leapfrog', 'k_mix_', 'k_map_back', 'k_vq_', 'k_data_inpaint', 'k_inpaint', 'k_sr', 'k_sgemm', 'k_sum_partials',
         'k_hamiltonian', 'k_metropolis', 'k_schedule', 'k_accept_commit', 'k_psnr', 'k_randn', 'k_uniform',
         'k_color', 'k_fwht', 'k_cs_', 'k_copy_probe', 'k_latent', 'k_mass', 'k_rank')
 
@@ -55,6 +55,59 @@ if p:
     top = set(r['Name'] for r in rows[:40])
     stats(p, os.path.join(here, f'{tag}_kernel_stats_e2e_top.csv'), lambda r: r['Name'] in top or any(k in r['Name'] for k in OURS))
 
+# steady-state table of the end-to-end run: only the dispatches between bench.py's two marker launches
+# (NHMC_PROFILE_MARK=1: one-block k_copy_probe right before and after the timed steps), i.e. no warm-up, no MIOpen
+# first-call fallbacks, no roofline / hot-path legs.  Run on the box (the trace is tens of MB); keeps a small csv.
+p = one('e2e/*/*_kernel_trace.csv')
+if p:
+    rows = list(csv.DictReader(open(p)))
+    gx = 'Grid_Size_X' if 'Grid_Size_X' in rows[0] else 'Grid_Size'
+    marks = [r for r in rows if 'k_copy_probe' in r['Kernel_Name'] and int(r[gx]) == 256]
+    if len(marks) >= 2:
+        t_lo, t_hi = int(marks[0]['End_Timestamp']), int(marks[1]['Start_Timestamp'])
+        steps = int(os.environ.get('NHMC_PROFILE_STEPS', '2'))
+        agg = defaultdict(lambda: [0, 0])
+
+        def family(n):
+            if any(k in n for k in OURS):
+                return 'nhmc HIP kernels'
+            low = n.lower()
+            if 'cijk_' in low or 'gemm' in low and 'conv' not in low and 'igemm' not in low:
+                return 'GEMM (rocBLAS / hipBLASLt: attention, linear)'
+            if any(k in low for k in ('conv', 'igemm', 'winograd', 'sp3asm', 'naive_')):
+                return 'MIOpen convolution'
+            if any(k in low for k in ('groupnorm', 'rowwisemoments', 'computefusedparams', 'group_norm', 'gammabeta', 'batch_norm', 'batchnorm')):
+                return 'GroupNorm (ATen)'
+            if 'softmax' in low:
+                return 'softmax (ATen)'
+            if any(k in low for k in ('elementwise', 'vectorized', 'cat', 'copy', 'fill', 'upsample', 'avg_pool', 'reduce', 'index')):
+                return 'ATen elementwise / copy / pool'
+            return 'other'
+        for r in rows:
+            st = int(r['Start_Timestamp'])
+            if t_lo <= st <= t_hi:
+                a = agg[short(r['Kernel_Name'])[:110]]
+                a[0] += 1
+                a[1] += int(r['End_Timestamp']) - st
+        total = sum(v[1] for v in agg.values())
+        fam = defaultdict(int)
+        for k, v in agg.items():
+            fam[family(k)] += v[1]
+        with open(os.path.join(here, f'{tag}_kernel_stats_e2e_steady.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow([f'# steady state: {steps} timed steps of bench.py (B = 64, U-Net in the loop), wall between markers '
+                        f'{(t_hi - t_lo) / 1e6:.1f} ms, summed kernel time {total / 1e6:.1f} ms'])
+            w.writerow(['family', 'ms_per_step', 'percent'])
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]):
+                w.writerow([k, f'{v / 1e6 / steps:.2f}', f'{100 * v / total:.2f}'])
+            w.writerow([])
+            w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage'])
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+                w.writerow([k, v[0], v[1], f'{v[1] / v[0]:.0f}', f'{100 * v[1] / total:.3f}'])
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[45:]:
+                if any(o in k for o in OURS):
+                    w.writerow([k, v[0], v[1], f'{v[1] / v[0]:.0f}', f'{100 * v[1] / total:.3f}'])
+
 acc = defaultdict(lambda: defaultdict(list))
 for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
     p = one(f'{sub}/*/*_counter_collection.csv')
@@ -74,6 +127,7 @@ if acc:
             if k.startswith('k_leapfrog<1, false'):
                 json.dump({'kernel': k, 'fetch_size_kib': fe, 'write_size_kib': wr,
                            'hbm_bytes_per_launch': (2 * fe + wr) * 1024,
+                           'source': f'profiles/{tag}_pmc_hbm.csv',
                            'note': 'FETCH_SIZE doubled (gfx950 wide-read correction), separate --pmc passes, source ' + tag},
                           open(os.path.join(here, 'traffic_leapfrog.json'), 'w'), indent=1)
 

@@ -78,3 +78,42 @@ def test_g5_probes_through_the_kernels(golden):
     hty = an.Ht(y.cuda()).cpu()
     assert _rel(hx[0, T(g['aniso_probe_m']).long()], T(g['aniso_Hx_probe'])) < 2e-5
     assert _rel(hty[0, T(g['aniso_probe_n']).long()], T(g['aniso_Hty_probe'])) < 2e-5
+
+
+def test_two_products_per_launch_equal_the_one_product_chain(golden):
+    """k_pair256 (the intermediate of each product pair stays in LDS) against the one-product-per-launch chain
+    (NHMC_SPECTRAL_PAIRS=0): same MFMA instruction, same k order -> the same bits for H, the data term and the form fused
+    with the last DDIM-step VJP."""
+    import os
+    import nhmc.kernels as K
+    from nhmc import operators
+    g = golden('g13_aniso_256.npz')
+    D = oops.SpectralBlurRef.multiplier_map(T(g['s_sorted']), T(g['perm'].astype(np.int64)), 3, 256)
+    op = operators.Deblurring2D.from_factors(T(g['U1']), T(g['U2']), T(g['V1']), T(g['V2']), D, 'cuda')
+    gen = torch.Generator().manual_seed(77)
+    B = 3
+    x = (torch.randn(B, 3, 256, 256, generator=gen) * 0.7).cuda()
+    e = torch.randn(B, 6, 256, 256, generator=gen).cuda()
+    y = torch.randn(B, 3 * 256 * 256, generator=gen).cuda()
+    at, atn = torch.full((B,), 0.5214230418).cuda(), torch.ones(B).cuda()
+    cur = K.ddim_mix_fwd(x, e, at, atn, final_clip=True)['xt_next']
+
+    def run():
+        ge = torch.zeros_like(e)
+        h = op.H(x)
+        loss, gr = op.data_term(x, y, apply_clip=True)
+        loss2, gx, _ = op.fused_last_vjp(x, e, at, atn, y, g_e_out=ge, xt_next=cur)
+        return h, loss, gr, loss2, gx, ge
+    old = os.environ.get('NHMC_SPECTRAL_PAIRS')
+    try:
+        os.environ['NHMC_SPECTRAL_PAIRS'] = '1'
+        a = run()
+        os.environ['NHMC_SPECTRAL_PAIRS'] = '0'
+        b = run()
+    finally:
+        os.environ.pop('NHMC_SPECTRAL_PAIRS', None)
+        if old is not None:
+            os.environ['NHMC_SPECTRAL_PAIRS'] = old
+    for u, v in zip(a, b):
+        assert torch.equal(u, v) or _rel(u.cpu(), v.cpu()) < 1e-6, _rel(u.cpu(), v.cpu())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])

@@ -106,4 +106,6 @@ def test_mass_loop_takes_the_oracles_decisions(tiny_score):
         margin = abs(float(U[it]) - min(1.0, float(np.exp(-trace['dH'][it]))))
         assert a == b or margin < 1e-3, (it, a, b, margin, trace['dH'][it], float(rec['dH'][0]))
         assert int(rec['epoch'][0]) == trace['epoch'][it]
-    assert res.samples.shape[1] == 35 and rel(res.samples[0], want) < 1e-3
+    err = rel(res.samples[0], want)
+    print(f'mass loop: returned samples rel err {err:.2e}')
+    assert res.samples.shape[1] == 35 and err < 1e-3
