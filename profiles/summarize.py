@@ -20,7 +20,7 @@ from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-OURS = ('k_leapfrog', 'k_mix_', 'k_map_back', 'k_vq_', 'k_data_inpaint', 'k_inpaint', 'k_sr', 'k_sgemm', 'k_sum_partials',
+OURS = ('k_leapfrog', 'k_mix_', 'k_map_back', 'k_vq_', 'k_gn_', 'k_pair', 'k_data_inpaint', 'k_inpaint', 'k_sr', 'k_sgemm', 'k_sum_partials',
         'k_hamiltonian', 'k_metropolis', 'k_schedule', 'k_accept_commit', 'k_psnr', 'k_randn', 'k_uniform',
         'k_color', 'k_fwht', 'k_cs_', 'k_copy_probe', 'k_latent', 'k_mass', 'k_rank')
 
