@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 // and immediately consumes it as the k-major left operand of the second product
 //     OUT[slab rows][:] = T1[:, slab]^T S2 (64 x 256),
 // so a pair of products costs one launch, one prologue and one epilogue, and T1 is never written.  4 blocks per image
-// (768 per pair at B = 64 = 3 per CU, one resident at a time: 128 KB of LDS), 8 waves per block = two per SIMD.
+// (768 per pair at B = 64 = 3 per CU; 64 KB of LDS each, so two are resident and drift apart: one block's slab staging
+// and epilogue overlap the other's MFMAs), 8 waves per block.
 // The main loops have NO block barrier: the operand every wave shares is resident in LDS for the whole phase (the S1
 // slab in phase 1, staged once; the T1 slab in phase 2), and the operand a wave needs alone (its 32 rows of IN, its 32
 // columns of S2) is read straight from global / L2 into MFMA fragments, 16 k-pairs ahead in registers, so waves drift
@@ -209,13 +210,15 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 // the 64 KB epilogue against 27 us of MFMA work, and one block fits a CU -- but it halves the launches and keeps
 // half of the intermediates (8T of 16T per chain) out of HBM.
 template <int EPI, bool PRECLIP>
-__global__ __launch_bounds__(512, 1) void k_pair256(
+__global__ __launch_bounds__(512, 2) void k_pair256(
     const float* __restrict__ IN, const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int channels, VjpArgs vj) {
   constexpr int D = 256, SL = 64, NW = 8, NT = 64 * NW, CHK = 16;       // CHK: k-pairs fetched ahead per register set
   extern __shared__ float lds[];
-  float* const slab = lds;                                  // [256][64]  T1[k'][r'], later the epilogue's [64][256] staging
-  float* const s1s = lds + D * SL;                          // [256][64]  S1[k][slab columns]
+  // ONE 64 KB region, three lives: S1[:, slab] during phase 1, T1[:, slab] during phase 2 (it lives in the accumulators
+  // until every wave has finished reading S1), the [64][256] output staging of the epilogue -> two blocks fit a CU
+  float* const slab = lds;                                  // [256][64]  T1[k'][r'] / [64][256] epilogue staging
+  float* const s1s = lds;                                   // [256][64]  S1[k][slab columns]
   const int total = gridDim.x;
   int logical = blockIdx.x;
   if ((total & 7) == 0) logical = (logical & 7) * (total >> 3) + (logical >> 3);   // the 4 slabs of an image share an XCD
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void k_pair256(
     }
   }
   // accumulators -> slab[k' = row of T1][r' = slab column]   (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 lh)
+  __syncthreads();                                          // every wave is done with the S1 slab the T1 slab overwrites
 #pragma unroll
   for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void k_pair256(
   }
 }
 
-constexpr int PAIR_LDS_BYTES = 2 * 256 * 64 * 4;            // T1 slab + S1 slab = 128 KB
+constexpr int PAIR_LDS_BYTES = 256 * 64 * 4;                // one 64 KB slab region (S1 slab, then T1 slab, then output staging)
 
 template <int EPI, bool PRECLIP>
 int pair256(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
