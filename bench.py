@@ -74,7 +74,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=None, tiny=False):
+def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=None, tiny=False, sigma0=SIGMA0_CLI):
     import nhmc.kernels as K
     from nhmc import operators, plugin, schedule, unet
     gen = torch.Generator().manual_seed(seed)
@@ -83,7 +83,7 @@ def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=N
         torch.manual_seed(seed)
         cfg = dict(unet.FFHQ_CONFIG, num_channels=32, num_head_channels=32) if tiny else unet.FFHQ_CONFIG
         model = unet.create_model(**cfg).to(device).eval().requires_grad_(False)
-    algo = plugin.HMC(model, op, 2 * SIGMA0_CLI)
+    algo = plugin.HMC(model, op, 2 * sigma0)
     b = torch.from_numpy(schedule.get_beta_schedule('linear', beta_start=1e-4, beta_end=0.02,
                                                     num_diffusion_timesteps=1000)).float().to(device)
     seq, seq_next = schedule.timestep_ladder(1000, TIMESTEPS)
@@ -91,9 +91,9 @@ def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=N
     x = K.randn_philox(shape, seed, chain_id0, 0, device=device)
     p = K.randn_philox(shape, seed, chain_id0, 1, device=device)
     x_true = K.randn_philox(shape, seed, chain_id0, 2, device=device).clamp_(-1, 1)
-    y = op.H(x_true) + (2 * SIGMA0_CLI) * torch.randn(B, op.M, device=device,
-                                                       generator=torch.Generator(device=device).manual_seed(seed + chain_id0))
-    return dict(op=op, algo=algo, b=b, seq=seq, seq_next=seq_next, x=x, p=p, y=y, model=model)
+    y = op.H(x_true) + (2 * sigma0) * torch.randn(B, op.M, device=device,
+                                                  generator=torch.Generator(device=device).manual_seed(seed + chain_id0))
+    return dict(op=op, algo=algo, b=b, seq=seq, seq_next=seq_next, x=x, p=p, y=y, model=model, sigma0=sigma0)
 
 
 def leapfrog_roofline(device, B, launches, n_elem=CH * DIM * DIM):
@@ -342,16 +342,17 @@ def degradation_leg(device, deg, model, B, chunk, steps=2):
     """configs[2] / configs[3]: the same step with another operator -- hot path, data-term roofline, a few end-to-end steps."""
     import nhmc.kernels as K
     from nhmc import sampler, sharding
-    prob = build_problem(device, B, 0, deg=deg, model=model)
+    sigma0 = {'deblur_aniso': 0.01}.get(deg, SIGMA0_CLI)               # BASELINE configs[3] quotes sigma_0 = 0.01
+    prob = build_problem(device, B, 0, deg=deg, model=model, sigma0=sigma0)
     eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device, chunk=chunk)
     eps = torch.full((B,), EPS, dtype=torch.float64, device=device)
-    sig = torch.full((B,), 2 * SIGMA0_CLI + 1.6, dtype=torch.float64, device=device)
+    sig = torch.full((B,), 2 * sigma0 + 1.6, dtype=torch.float64, device=device)
     ws = K.leapfrog_ws(B, CH * DIM * DIM, device)
     dt, _, _ = timed_steps(eng, prob['x'], prob['p'], prob['y'], eps, sig, ws, 1, steps, 1, 0, sharding, device)
     hot = hot_path_only(device, prob, B, 20, chunk=chunk)
     return dict(value=round(B * steps / dt, 3), unit='chain-steps/s', steps=steps, ms_per_step=round(1e3 * dt / steps, 2),
                 hot_path_only=dict(value=round(hot['value'], 1), ms_per_step=round(hot['ms_per_step'], 4)),
-                roofline=data_term_roofline(device, prob, B), M=int(prob['op'].M))
+                roofline=data_term_roofline(device, prob, B), M=int(prob['op'].M), sigma_0=sigma0)
 
 
 def latent_main(args):

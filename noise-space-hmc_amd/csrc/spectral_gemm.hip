@@ -209,11 +209,12 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 // So the pair form does not beat the chain on time -- each block still serialises ~16 us of slab staging, barriers and
 // the 64 KB epilogue against 27 us of MFMA work, and one block fits a CU -- but it halves the launches and keeps
 // half of the intermediates (8T of 16T per chain) out of HBM.
-template <int EPI, bool PRECLIP>
-__global__ __launch_bounds__(512, 2) void k_pair256(
+template <int EPI, bool PRECLIP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_pair256(
     const float* __restrict__ IN, const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int channels, VjpArgs vj) {
-  constexpr int D = 256, SL = 64, NW = 8, NT = 64 * NW, CHK = 16;       // CHK: k-pairs fetched ahead per register set
+  constexpr int D = 256, SL = 64, NT = 64 * NW, CHK = 16;   // CHK: k-pairs fetched ahead per register set
+  constexpr int F = 8 / NW;                                  // 32-wide fragments of the wave's private operand (NW = 4: 2 x 2 MFMA tiles)
   extern __shared__ float lds[];
   // ONE 64 KB region, three lives: S1[:, slab] during phase 1, T1[:, slab] during phase 2 (it lives in the accumulators
   // until every wave has finished reading S1), the [64][256] output staging of the epilogue -> two blocks fit a CU
@@ -231,27 +232,35 @@ __global__ __launch_bounds__(512, 2) void k_pair256(
     const int idx = tid + v * NT, kk = idx / (SL / 4), c4 = idx % (SL / 4);
     *reinterpret_cast<nhmc_v4f*>(&s1s[kk * SL + c4 * 4]) = *reinterpret_cast<const nhmc_v4f*>(&S1[(int64_t)kk * D + q * SL + c4 * 4]);
   }
-  f32x16 acc[2];
+  f32x16 acc[F][2];                                         // phase 1: [private row fragment][slab column fragment]; phase 2: [private column fragment][slab row fragment]
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int f = 0; f < F; ++f)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][b][r] = 0.0f;
 
-  // ------------------------------------------------ phase 1: T1[32 wave rows][slab] = IN^T S1[:, slab] ---------------
+  // ------------------------------------------------ phase 1: T1[wave rows][slab] = IN^T S1[:, slab] ------------------
   {
-    const float* __restrict__ ap = Ximg + wave * 32 + lr + (int64_t)lh * D;     // a(k-pair j) = ap[2 j D]: IN[2j + lh][row]
-    float f0[CHK], f1[CHK];
-    auto fetch = [&](float (&fa)[CHK], int c) {
+    const float* __restrict__ ap = Ximg + wave * (32 * F) + lr + (int64_t)lh * D;  // a(k-pair j, f) = ap[2 j D + 32 f]: IN[2j + lh][row]
+    float f0[CHK][F], f1[CHK][F];
+    auto fetch = [&](float (&fa)[CHK][F], int c) {
 #pragma unroll
-      for (int j = 0; j < CHK; ++j) fa[j] = ap[(int64_t)(2 * (c + j)) * D];
+      for (int j = 0; j < CHK; ++j)
+#pragma unroll
+        for (int f = 0; f < F; ++f) fa[j][f] = ap[(int64_t)(2 * (c + j)) * D + 32 * f];
     };
-    auto compute = [&](const float (&fa)[CHK], int c) {
+    auto compute = [&](const float (&fa)[CHK][F], int c) {
 #pragma unroll
       for (int j = 0; j < CHK; ++j) {
         const int kk = 2 * (c + j);
-        const float a = PRECLIP ? nhmc_clip1(fa[j]) : fa[j];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s1s[(kk + lh) * SL + lr], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s1s[(kk + lh) * SL + 32 + lr], acc[1], 0, 0, 0);
+        const float b0 = s1s[(kk + lh) * SL + lr], b1 = s1s[(kk + lh) * SL + 32 + lr];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          const float a = PRECLIP ? nhmc_clip1(fa[j][f]) : fa[j][f];
+          acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[f][0], 0, 0, 0);
+          acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[f][1], 0, 0, 0);
+        }
       }
     };
     fetch(f0, 0);
@@ -266,49 +275,56 @@ __global__ __launch_bounds__(512, 2) void k_pair256(
   // accumulators -> slab[k' = row of T1][r' = slab column]   (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 lh)
   __syncthreads();                                          // every wave is done with the S1 slab the T1 slab overwrites
 #pragma unroll
-  for (int fb = 0; fb < 2; ++fb)
+  for (int f = 0; f < F; ++f)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      slab[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SL + fb * 32 + lr] = acc[fb][r];
-      acc[fb][r] = 0.0f;
-    }
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        slab[((wave * F + f) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SL + fb * 32 + lr] = acc[f][fb][r];
+        acc[f][fb][r] = 0.0f;
+      }
 
-  // ------------------------------------------------ phase 2: OUT[slab][32 wave columns] = T1[:, slab]^T S2 -----------
+  // ------------------------------------------------ phase 2: OUT[slab][wave columns] = T1[:, slab]^T S2 --------------
   {
-    const float* __restrict__ bp = S2 + wave * 32 + lr + (int64_t)lh * D;       // b(k-pair j) = bp[2 j D]: S2[2j + lh][col]
-    float f0[CHK], f1[CHK];
+    const float* __restrict__ bp = S2 + wave * (32 * F) + lr + (int64_t)lh * D;    // b(k-pair j, f) = bp[2 j D + 32 f]: S2[2j + lh][col]
+    float f0[CHK][F], f1[CHK][F];
+    auto fetch = [&](float (&fb)[CHK][F], int c) {
 #pragma unroll
-    for (int j = 0; j < CHK; ++j) f0[j] = bp[(int64_t)(2 * j) * D];
+      for (int j = 0; j < CHK; ++j)
+#pragma unroll
+        for (int f = 0; f < F; ++f) fb[j][f] = bp[(int64_t)(2 * (c + j)) * D + 32 * f];
+    };
+    auto compute = [&](const float (&fb)[CHK][F], int c) {
+#pragma unroll
+      for (int j = 0; j < CHK; ++j) {
+        const int kk = 2 * (c + j);
+        const float a0 = slab[(kk + lh) * SL + lr], a1 = slab[(kk + lh) * SL + 32 + lr];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[j][f], acc[f][0], 0, 0, 0);
+          acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[j][f], acc[f][1], 0, 0, 0);
+        }
+      }
+    };
+    fetch(f0, 0);
     __syncthreads();                                        // T1 slab complete
     for (int c0 = 0; c0 < D / 2; c0 += 2 * CHK) {
-#pragma unroll
-      for (int j = 0; j < CHK; ++j) f1[j] = bp[(int64_t)(2 * (c0 + CHK + j)) * D];
-#pragma unroll
-      for (int j = 0; j < CHK; ++j) {
-        const int kk = 2 * (c0 + j);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + lr], f0[j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + 32 + lr], f0[j], acc[1], 0, 0, 0);
-      }
-      if (c0 + 2 * CHK < D / 2) {
-#pragma unroll
-        for (int j = 0; j < CHK; ++j) f0[j] = bp[(int64_t)(2 * (c0 + 2 * CHK + j)) * D];
-      }
-#pragma unroll
-      for (int j = 0; j < CHK; ++j) {
-        const int kk = 2 * (c0 + CHK + j);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + lr], f1[j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(kk + lh) * SL + 32 + lr], f1[j], acc[1], 0, 0, 0);
-      }
+      fetch(f1, c0 + CHK);
+      compute(f0, c0);
+      if (c0 + 2 * CHK < D / 2) fetch(f0, c0 + 2 * CHK);
+      compute(f1, c0 + CHK);
     }
   }
 
   // ------------------------------------------------ epilogue: [64 rows][256 cols] through the slab's 64 KB -----------
   __syncthreads();                                          // every wave is done reading the T1 slab
 #pragma unroll
-  for (int fa = 0; fa < 2; ++fa)
+  for (int f = 0; f < F; ++f)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      slab[(fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + wave * 32 + lr] = acc[fa][r];
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        slab[(fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + (wave * F + f) * 32 + lr] = acc[f][fa][r];
   __syncthreads();
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * D * D;
@@ -376,21 +392,29 @@ __global__ __launch_bounds__(512, 2) void k_pair256(
 
 constexpr int PAIR_LDS_BYTES = 256 * 64 * 4;                // one 64 KB slab region (S1 slab, then T1 slab, then output staging)
 
-template <int EPI, bool PRECLIP>
-int pair256(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
-            int n_img, int channels, hipStream_t st, VjpArgs vj = VjpArgs{}) {
+template <int EPI, bool PRECLIP, int NW>
+int pair256_nw(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
+               int n_img, int channels, hipStream_t st, VjpArgs vj) {
   static bool attr_set[64] = {};                             // raise the dynamic-LDS limit of this instantiation once per device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair256<EPI, PRECLIP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair256<EPI, PRECLIP, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES) != hipSuccess)
       return NHMC_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  NHMC_LAUNCH((k_pair256<EPI, PRECLIP>), dim3((unsigned)(4 * n_img)), dim3(512), PAIR_LDS_BYTES, st, IN, S1, S2, OUT, Dmap, aux,
-              ws, channels, vj);
+  NHMC_LAUNCH((k_pair256<EPI, PRECLIP, NW>), dim3((unsigned)(4 * n_img)), dim3(64 * NW), PAIR_LDS_BYTES, st, IN, S1, S2, OUT,
+              Dmap, aux, ws, channels, vj);
   return nhmc_launch_status();
+}
+
+template <int EPI, bool PRECLIP>
+int pair256(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
+            int n_img, int channels, hipStream_t st, VjpArgs vj = VjpArgs{}) {
+  const char* v = getenv("NHMC_PAIR_WAVES");                 // experiment switch (tools/pair_bench.py): 4 waves = 2 x 2 MFMA tiles per wave
+  if (v && v[0] == '4') return pair256_nw<EPI, PRECLIP, 4>(IN, S1, S2, OUT, Dmap, aux, ws, n_img, channels, st, vj);
+  return pair256_nw<EPI, PRECLIP, 8>(IN, S1, S2, OUT, Dmap, aux, ws, n_img, channels, st, vj);
 }
 
 int tile_of2(int R, int C) { return (R % 128 == 0 && C % 128 == 0) ? 128 : ((R % 64 == 0 && C % 64 == 0) ? 64 : 32); }
