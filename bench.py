@@ -58,7 +58,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--chunk', type=int, default=32, help='chains per score-network call (activation memory)')
+    ap.add_argument('--chunk', type=int, default=None,
+                    help='chains per score-network call (activation memory); default: the whole batch -- with the fused GroupNorm '
+                         'kernels the three autograd graphs of 64 chains fit the 288 GB (round 1 needed 32)')
     ap.add_argument('--batch', type=int, default=None, help='chains per GPU (BASELINE: 64; 16 with --latent)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-by-deg', action='store_true', help='skip the sr4 / deblur_aniso legs')
@@ -413,7 +415,7 @@ def latent_main(args):
             'config': {'workload': f'BASELINE configs[4]: FFHQ-latent [{model.channels},64,64] (the reference config has 3 latent '
                                    f'channels; BASELINE.json says 4), hmc_latent, inpaint_random sigma_0=0.05 eps=0.1 sigma_y=0.5 '
                                    f'timesteps=3, {B} chains per GPU, LDM U-Net (224 ch) + VQ-f4 decoder (128 ch, 8192 codes) random-init fp32',
-                       'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
+                       'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk or B,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
             'roofline': dict(bound='hbm', achieved=round(roof['achieved'], 1), peak=HBM_PEAK_GBS, unit='GB/s',
                              frac=round(roof['achieved'] / HBM_PEAK_GBS, 4), traffic=None, kernel=roof['kernel'],
@@ -451,6 +453,13 @@ def main():
     B = args.batch or B_PER_GPU
     lo = rank * B                                                      # global chain ids of this rank (weak scaling)
     prob = build_problem(device, B, lo, deg=args.deg, tiny=args.tiny_score)
+    if args.chunk is None:
+        # score chunk = the whole batch when its three autograd graphs fit: measured 3.45 GiB per chain with the fused
+        # GroupNorm kernels (220.8 GiB peak at 64 chains); otherwise halves.  Same decision on every rank (same cards).
+        free = torch.cuda.mem_get_info(device)[0] / 2 ** 30
+        args.chunk = B
+        while args.chunk > 1 and not args.tiny_score and 3.45 * 1.12 * args.chunk > free:
+            args.chunk = (args.chunk + 1) // 2
     eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device,
                                  chunk=args.chunk)
     x, p, y = prob['x'], prob['p'], prob['y']
@@ -462,7 +471,18 @@ def main():
     ms_per_step = value = gather = None
     in_situ = []
     if not args.kernel_only:
-        dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
+        try:
+            dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
+        except torch.OutOfMemoryError:
+            if world > 1:
+                raise                                               # ranks must stay in step: rerun with --chunk 32
+            eng = None
+            torch.cuda.empty_cache()
+            args.chunk = (args.chunk + 1) // 2
+            print(f'[bench] out of memory at one score chunk; retrying with --chunk {args.chunk}', file=sys.stderr, flush=True)
+            eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device,
+                                         chunk=args.chunk)
+            dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
         ms_per_step = 1e3 * dt / args.steps
         value = world * B * args.steps / dt
         # the one collective of the design: per-chain results gathered once, after the timed region (RCCL over xGMI at N > 1)
@@ -485,7 +505,7 @@ def main():
             roof['in_situ_chains_per_launch'] = chains
             roof['in_situ_gbs'] = 6 * chains * N * 4 / (roof['in_situ_us'] * 1e-6) / 1e9
             roof['in_situ_frac'] = roof['in_situ_gbs'] / HBM_PEAK_GBS
-            roof['in_situ_note'] = ('per-launch event pairs inside the timed steps: one launch per score chunk, with the second '
+            roof['in_situ_note'] = ('per-launch event pairs inside the timed steps (one launch per score chunk), with the second '
                                     'gradient pointer (R x,p,g,g2 + W x,p = 6T = 24 B/element), caches cold after the score network')
         traffic = source = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_leapfrog.json')
@@ -517,7 +537,7 @@ def main():
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
             'roofline': roofline, 'hot_path_only': hot, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
-            'cpu_baseline': cpu,
+            'peak_memory_gib': round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1), 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     sharding.barrier()
