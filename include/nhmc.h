@@ -355,16 +355,24 @@ int nhmc_vq_nearest(const float* z, const float* codebook, float* z_q, int32_t* 
  *   u = ((x - mean_g) rstd_g gamma_c + beta_c) (1 + scale_bc) + shift_bc ;   y = act ? u sigmoid(u) : u
  * x, y, dy, dx: [n][channels][hw] contiguous fp32 (hw % 4 == 0); gamma, beta: [channels];
  * film (nullable): [n][film_stride] with scale at [c] and shift at [channels + c] (the reference's emb_out.chunk(2)).
+ * pre (nullable): x + pre[b * pre_stride + c] is what gets normalised -- the bias of the convolution that produced x
+ *   (pre_stride = 0) or bias + a per-sample embedding term ([n][pre_stride], openaimodel.py:257 `h = h + emb_out`), so the
+ *   producer runs without its broadcast add pass.
  * ws: double[n * groups][splits][2] partial sums (splits = nhmc_gn_splits(...)); the forward's ws is an input of the
  * backward (mean / rstd are re-derived from it; nothing else is saved).  Only dx is produced: the networks are frozen.
  * ---------------------------------------------------------------------------------- */
 int nhmc_gn_splits(int n, int channels, int groups, int64_t hw);
 int nhmc_gn_act_fwd(const float* x, const float* gamma, const float* beta, const float* film, int64_t film_stride,
-                    float eps, int act, float* y, double* ws, int splits, int n, int channels, int groups,
-                    int64_t hw, nhmc_stream_t stream);
+                    const float* pre, int64_t pre_stride, float eps, int act, float* y, double* ws, int splits,
+                    int n, int channels, int groups, int64_t hw, nhmc_stream_t stream);
 int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* film,
-                    int64_t film_stride, float eps, int act, const double* fwd_ws, float* dx, double* ws,
-                    int splits, int n, int channels, int groups, int64_t hw, nhmc_stream_t stream);
+                    int64_t film_stride, const float* pre, int64_t pre_stride, float eps, int act,
+                    const double* fwd_ws, float* dx, double* ws, int splits, int n, int channels, int groups,
+                    int64_t hw, nhmc_stream_t stream);
+/* out = (h + bias_c) + other, [n][channels][hw]: a convolution's bias folded into the residual add that follows it
+ * (unet_ffhq.py:321).  Its backward is the identity towards both h and other. */
+int nhmc_bias_add2(const float* h, const float* bias, const float* other, float* out, int n, int channels,
+                   int64_t hw, nhmc_stream_t stream);
 
 /* PSNR of clamp((xt+1)/2,0,1) against clamp((x_orig+1)/2,0,1)   main_sampling.py:738-739
  * ws: double[n_chains][nhmc_data_tiles(n_elem)]. */

@@ -25,6 +25,9 @@ constexpr int GN_TILE = NHMC_BLOCK * 2 * 4;      // elements per block: 2 float4
 struct GnArgs {
   const float* gamma; const float* beta;          // [C]
   const float* film; int64_t film_stride;         // nullable: [B][film_stride] with scale at [c], shift at [C + c]
+  const float* pre; int64_t pre_stride;           // nullable: x + pre[b * pre_stride + c] is what gets normalised (the bias of
+                                                  // the convolution that produced x, + a per-sample embedding term): the
+                                                  // producer then runs without its broadcast bias-add pass
   int C, G; int64_t hw; float eps; int act; int splits;
 };
 
@@ -51,21 +54,22 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_stats(const float4* __restric
   for (int64_t q = lo + threadIdx.x; q < hi; q += NHMC_BLOCK) {
     const float4 xv = x[base + q];
     const float* xe = reinterpret_cast<const float*>(&xv);
+    const int ch = g * cpg + (int)((q * 4) / a.hw);
+    const float pb = a.pre ? a.pre[(int64_t)b * a.pre_stride + ch] : 0.0f;
     if (!BWD) {
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { t0 += xe[c]; t1 += xe[c] * xe[c]; }
+      for (int c = 0; c < 4; ++c) { const float v = xe[c] + pb; t0 += v; t1 += v * v; }
       s0 += (double)t0; s1 += (double)t1;
     } else {
       const float4 dv = dy[base + q];
       const float* de = reinterpret_cast<const float*>(&dv);
-      const int ch = g * cpg + (int)((q * 4) / a.hw);
       float ga = a.gamma[ch], be = a.beta[ch];
       if (a.film) { const float sc = 1.0f + a.film[(int64_t)b * a.film_stride + ch]; ga *= sc; be = be * sc + a.film[(int64_t)b * a.film_stride + a.C + ch]; }
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float xh = (xe[c] - mean) * rstd;
+        const float xh = ((xe[c] + pb) - mean) * rstd;
         float du = de[c];
         if (a.act) { const float u = xh * ga + be, sg = gn_sigmoid(u); du = du * (sg * (1.0f + u * (1.0f - sg))); }
         const float dxh = du * ga;
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_apply(const float4* __restric
     const float4 xv = x[base + q];
     const float* xe = reinterpret_cast<const float*>(&xv);
     const int ch = g * cpg + (int)((q * 4) / a.hw);
+    const float pb = a.pre ? a.pre[(int64_t)b * a.pre_stride + ch] : 0.0f;
     float ga = a.gamma[ch], be = a.beta[ch];
     if (a.film) { const float sc = 1.0f + a.film[(int64_t)b * a.film_stride + ch]; ga *= sc; be = be * sc + a.film[(int64_t)b * a.film_stride + a.C + ch]; }
     float4 o;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_apply(const float4* __restric
     if (!BWD) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float u = ((xe[c] - mean) * rstd) * ga + be;
+        const float u = (((xe[c] + pb) - mean) * rstd) * ga + be;
         oe[c] = a.act ? u * gn_sigmoid(u) : u;
       }
     } else {
@@ -125,13 +130,31 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_apply(const float4* __restric
       const float* de = reinterpret_cast<const float*>(&dv);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float xh = (xe[c] - mean) * rstd;
+        const float xh = ((xe[c] + pb) - mean) * rstd;
         float du = de[c];
         if (a.act) { const float u = xh * ga + be, sg = gn_sigmoid(u); du = du * (sg * (1.0f + u * (1.0f - sg))); }
         oe[c] = rstd * ((du * ga - m0) - xh * m1);
       }
     }
     out[base + q] = o;
+  }
+}
+
+// out = (h + bias_c) + other: the bias of the convolution that produced h folded into the residual add that follows it
+// (unet_ffhq.py:321 `self.skip_connection(x) + h`): one 2R + 1W pass instead of a broadcast bias add (R + W) and an add.
+__global__ __launch_bounds__(NHMC_BLOCK) void k_bias_add2(const float4* __restrict__ h, const float* __restrict__ bias,
+                                                          const float4* __restrict__ other, float4* __restrict__ out,
+                                                          int64_t n4, int64_t hw4, int C) {
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * 2) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    const float bc = bias[(int)((q / hw4) % C)];
+    const float4 a = h[q], b = other[q];
+    float4 o;
+    o.x = (a.x + bc) + b.x; o.y = (a.y + bc) + b.y; o.z = (a.z + bc) + b.z; o.w = (a.w + bc) + b.w;
+    out[q] = o;
   }
 }
 
@@ -155,12 +178,12 @@ extern "C" int nhmc_gn_splits(int n, int channels, int groups, int64_t hw) {
 }
 
 extern "C" int nhmc_gn_act_fwd(const float* x, const float* gamma, const float* beta, const float* film, int64_t film_stride,
-                               float eps, int act, float* y, double* ws, int splits, int n, int channels, int groups,
-                               int64_t hw, nhmc_stream_t stream) {
+                               const float* pre, int64_t pre_stride, float eps, int act, float* y, double* ws, int splits,
+                               int n, int channels, int groups, int64_t hw, nhmc_stream_t stream) {
   int rc = gn_check(x, gamma, beta, n, channels, groups, hw, splits);
   if (rc) return rc;
   if (!y || !ws || !nhmc_aligned16(y)) return NHMC_ERR_ARG;
-  const GnArgs a{gamma, beta, film, film_stride, channels, groups, hw, eps, act, splits};
+  const GnArgs a{gamma, beta, film, film_stride, pre, pre_stride, channels, groups, hw, eps, act, splits};
   const int64_t n4 = (int64_t)(channels / groups) * hw / 4;
   hipStream_t st = nhmc_s(stream);
   NHMC_LAUNCH(k_gn_stats<false>, dim3((unsigned)splits, (unsigned)(n * groups)), dim3(NHMC_BLOCK), 0, st, (const float4*)x,
@@ -172,12 +195,13 @@ extern "C" int nhmc_gn_act_fwd(const float* x, const float* gamma, const float* 
 }
 
 extern "C" int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* film,
-                               int64_t film_stride, float eps, int act, const double* fwd_ws, float* dx, double* ws,
-                               int splits, int n, int channels, int groups, int64_t hw, nhmc_stream_t stream) {
+                               int64_t film_stride, const float* pre, int64_t pre_stride, float eps, int act,
+                               const double* fwd_ws, float* dx, double* ws, int splits, int n, int channels, int groups,
+                               int64_t hw, nhmc_stream_t stream) {
   int rc = gn_check(x, gamma, beta, n, channels, groups, hw, splits);
   if (rc) return rc;
   if (!dy || !fwd_ws || !dx || !ws || !nhmc_aligned16(dy) || !nhmc_aligned16(dx)) return NHMC_ERR_ARG;
-  const GnArgs a{gamma, beta, film, film_stride, channels, groups, hw, eps, act, splits};
+  const GnArgs a{gamma, beta, film, film_stride, pre, pre_stride, channels, groups, hw, eps, act, splits};
   const int64_t n4 = (int64_t)(channels / groups) * hw / 4;
   hipStream_t st = nhmc_s(stream);
   NHMC_LAUNCH(k_gn_stats<true>, dim3((unsigned)splits, (unsigned)(n * groups)), dim3(NHMC_BLOCK), 0, st, (const float4*)x,
@@ -185,5 +209,17 @@ extern "C" int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gam
   if ((rc = nhmc_launch_status())) return rc;
   NHMC_LAUNCH(k_gn_apply<true>, dim3((unsigned)((n4 + NHMC_BLOCK * 2 - 1) / (NHMC_BLOCK * 2)), (unsigned)(n * groups)),
               dim3(NHMC_BLOCK), 0, st, (const float4*)x, (const float4*)dy, fwd_ws, ws, a, (float4*)dx);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_bias_add2(const float* h, const float* bias, const float* other, float* out, int n, int channels,
+                              int64_t hw, nhmc_stream_t stream) {
+  if (!h || !bias || !other || !out || n <= 0 || channels <= 0 || hw <= 0) return NHMC_ERR_ARG;
+  if (hw % 4) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(h) || !nhmc_aligned16(other) || !nhmc_aligned16(out)) return NHMC_ERR_ALIGN;
+  const int64_t n4 = (int64_t)n * channels * hw / 4, blocks = (n4 + NHMC_BLOCK * 2 - 1) / (NHMC_BLOCK * 2);
+  if (blocks > 0x7fffffff) return NHMC_ERR_SHAPE;
+  NHMC_LAUNCH(k_bias_add2, dim3((unsigned)blocks), dim3(NHMC_BLOCK), 0, nhmc_s(stream), (const float4*)h, bias,
+              (const float4*)other, (float4*)out, n4, hw / 4, channels);
   return nhmc_launch_status();
 }

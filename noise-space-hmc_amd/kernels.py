@@ -606,45 +606,64 @@ def vq_nearest(z, codebook):
     return zq, idx
 
 
-def _gn_shape(x, gamma, groups, film):
+def _gn_shape(x, gamma, groups, film, pre):
     B, Cc = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
     if gamma.numel() != Cc or Cc % groups or hw % 4:
         raise _lib.NhmcError(f'fused GroupNorm: shape {tuple(x.shape)} / {groups} groups not covered (hw % 4 == 0, C % G == 0)')
-    stride = 0
+    stride = pstride = 0
     if film is not None:
         if film.dim() != 2 or film.shape != (B, 2 * Cc) or film.stride(1) != 1:
             raise _lib.NhmcError('fused GroupNorm: film must be [B, 2C] (scale | shift) with unit inner stride')
         stride = film.stride(0)
-    return B, Cc, hw, stride
+    if pre is not None:
+        if pre.dtype != torch.float32 or not pre.is_cuda or pre.stride(-1) != 1 or pre.shape not in ((Cc,), (B, Cc)):
+            raise _lib.NhmcError('fused GroupNorm: pre must be float32 [C] or [B, C] on the GPU')
+        pstride = pre.stride(0) if pre.dim() == 2 else 0
+    return B, Cc, hw, stride, pstride
 
 
-def gn_act_fwd(x, gamma, beta, groups, eps, act, film=None):
-    """GroupNorm (+ FiLM) (+ SiLU) forward -> (y, ws, splits); ws feeds gn_act_bwd."""
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def gn_act_fwd(x, gamma, beta, groups, eps, act, film=None, pre=None):
+    """GroupNorm of (x + pre) (+ FiLM) (+ SiLU) forward -> (y, ws, splits); ws feeds gn_act_bwd."""
     lib = _lib.load()
-    B, Cc, hw, stride = _gn_shape(x, gamma, groups, film)
+    B, Cc, hw, stride, pstride = _gn_shape(x, gamma, groups, film, pre)
     splits = lib.nhmc_gn_splits(B, Cc, groups, hw)
     ws = torch.empty(B * groups * splits * 2, dtype=torch.float64, device=x.device)
     y = torch.empty_like(x)
     rc = lib.nhmc_gn_act_fwd(_p(x, torch.float32, 'x'), _p(gamma, torch.float32, 'gamma'), _p(beta, torch.float32, 'beta'),
-                             C.c_void_p(film.data_ptr()) if film is not None else C.c_void_p(0), stride, float(eps), int(act),
-                             _p(y), _p(ws), splits, B, Cc, groups, hw, _stream())
+                             _ptr(film), stride, _ptr(pre), pstride, float(eps), int(act), _p(y), _p(ws), splits, B, Cc, groups,
+                             hw, _stream())
     _lib.check(rc, 'nhmc_gn_act_fwd')
     return y, ws, splits
 
 
-def gn_act_bwd(x, dy, gamma, beta, groups, eps, act, film, fwd_ws, splits):
-    """Input gradient of gn_act_fwd (parameters and FiLM terms are constants of the path)."""
+def gn_act_bwd(x, dy, gamma, beta, groups, eps, act, film, fwd_ws, splits, pre=None):
+    """Input gradient of gn_act_fwd (parameters, FiLM and pre-bias terms are constants of the path)."""
     lib = _lib.load()
-    B, Cc, hw, stride = _gn_shape(x, gamma, groups, film)
+    B, Cc, hw, stride, pstride = _gn_shape(x, gamma, groups, film, pre)
     ws = torch.empty(B * groups * splits * 2, dtype=torch.float64, device=x.device)
     dx = torch.empty_like(x)
     rc = lib.nhmc_gn_act_bwd(_p(x, torch.float32, 'x'), _p(dy, torch.float32, 'dy'), _p(gamma, torch.float32, 'gamma'),
-                             _p(beta, torch.float32, 'beta'), C.c_void_p(film.data_ptr()) if film is not None else C.c_void_p(0),
-                             stride, float(eps), int(act), _p(fwd_ws, torch.float64), _p(dx), _p(ws), splits, B, Cc, groups, hw,
-                             _stream())
+                             _p(beta, torch.float32, 'beta'), _ptr(film), stride, _ptr(pre), pstride, float(eps), int(act),
+                             _p(fwd_ws, torch.float64), _p(dx), _p(ws), splits, B, Cc, groups, hw, _stream())
     _lib.check(rc, 'nhmc_gn_act_bwd')
     return dx
+
+
+def bias_add2(h, bias, other):
+    """(h + bias[c]) + other for [B, C, ...] tensors: a convolution's bias folded into the residual add after it."""
+    lib = _lib.load()
+    if h.shape != other.shape or bias.numel() != h.shape[1]:
+        raise _lib.NhmcError('bias_add2: shape mismatch')
+    out = torch.empty_like(h)
+    rc = lib.nhmc_bias_add2(_p(h, torch.float32, 'h'), _p(bias, torch.float32, 'bias'), _p(other, torch.float32, 'other'),
+                            _p(out), h.shape[0], h.shape[1], h[0, 0].numel(), _stream())
+    _lib.check(rc, 'nhmc_bias_add2')
+    return out
 
 
 def psnr(xt, x_orig):

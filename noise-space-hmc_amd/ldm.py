@@ -32,7 +32,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import kernels as K
-from .unet import AttentionBlock, Stage, group_norm_act, sinusoid, sinusoid_freqs
+from .unet import AttentionBlock, Stage, _BiasAdd2, conv_nobias, fused_glue, group_norm_act, sinusoid, sinusoid_freqs
 
 # configs/config_ffhq_latent.yml:45-80
 FFHQ_LDM_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=(8, 4, 2),
@@ -81,8 +81,15 @@ class AddEmbResBlock(nn.Module):
         self.skip_connection = nn.Identity() if out_ch == ch else nn.Conv2d(ch, out_ch, 1)
 
     def forward(self, x, emb):
-        h = self.in_layers[2](group_norm_act(self.in_layers[0], x)) + self.emb_layers(emb)[:, :, None, None]
-        return self.skip_connection(x) + self.out_layers[3](group_norm_act(self.out_layers[0], h))
+        conv1, conv2, e = self.in_layers[2], self.out_layers[3], self.emb_layers(emb)
+        h = group_norm_act(self.in_layers[0], x)
+        if fused_glue(h, conv1.bias, conv2.bias, e):
+            # conv1's bias and the embedding term (h = conv(..) + emb_out, openaimodel.py:257) enter the next GroupNorm's
+            # load as one [B, C] term; conv2's bias enters the residual add
+            h = group_norm_act(self.out_layers[0], conv_nobias(conv1, h), pre=(e + conv1.bias).contiguous())
+            return _BiasAdd2.apply(conv_nobias(conv2, h), conv2.bias, self.skip_connection(x))
+        h = conv1(h) + e[:, :, None, None]
+        return self.skip_connection(x) + conv2(group_norm_act(self.out_layers[0], h))
 
 
 class LDMUNet(nn.Module):
@@ -169,9 +176,13 @@ class PlainResBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
-        h = self.conv1(group_norm_act(self.norm1, x, act_fn=_swish))     # Normalize + x sigmoid(x)
-        h = self.conv2(group_norm_act(self.norm2, h, act_fn=_swish))
-        return (self.nin_shortcut(x) if hasattr(self, 'nin_shortcut') else x) + h
+        h = group_norm_act(self.norm1, x, act_fn=_swish)                 # Normalize + x sigmoid(x)
+        sc = self.nin_shortcut(x) if hasattr(self, 'nin_shortcut') else x
+        if fused_glue(h, self.conv1.bias, self.conv2.bias):
+            h = group_norm_act(self.norm2, conv_nobias(self.conv1, h), act_fn=_swish, pre=self.conv1.bias)
+            return _BiasAdd2.apply(conv_nobias(self.conv2, h), self.conv2.bias, sc)
+        h = self.conv2(group_norm_act(self.norm2, self.conv1(h), act_fn=_swish))
+        return sc + h
 
 
 class SpatialSelfAttention(nn.Module):

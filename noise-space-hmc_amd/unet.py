@@ -38,43 +38,70 @@ def sinusoid(t, dim, freqs=None):
 
 
 class _GroupNormAct(torch.autograd.Function):
-    """y = act(GroupNorm(x) (1 + scale) + shift) on the fused HIP kernels (csrc/gn_act.hip): 2 reads + 1 write forward,
+    """y = act(GroupNorm(x + pre) (1 + scale) + shift) on the fused HIP kernels (csrc/gn_act.hip): 2 reads + 1 write forward,
     4 reads + 1 write for the input gradient, nothing but x saved -- against 5R + 4W / 7R + 3W for the ATen op sequence
     the reference's GroupNorm32 + scale-shift + SiLU lowers to (unet_ffhq.py:310-321)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, groups, eps, act):
+    def forward(ctx, x, gamma, beta, film, pre, groups, eps, act):
         xc = x if x.is_contiguous() else x.contiguous()
-        y, ws, splits = K.gn_act_fwd(xc, gamma, beta, groups, eps, act, film)
-        ctx.save_for_backward(xc, gamma, beta, ws, *([film] if film is not None else []))
+        y, ws, splits = K.gn_act_fwd(xc, gamma, beta, groups, eps, act, film, pre)
+        ctx.save_for_backward(xc, gamma, beta, ws)
+        ctx.consts = (film, pre)                              # constants of the path (no gradient flows into them)
         ctx.meta = (groups, eps, act, splits)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, gamma, beta, ws, *rest = ctx.saved_tensors
+        xc, gamma, beta, ws = ctx.saved_tensors
         groups, eps, act, splits = ctx.meta
+        film, pre = ctx.consts
         dy = dy if dy.is_contiguous() else dy.contiguous()
-        dx = K.gn_act_bwd(xc, dy, gamma, beta, groups, eps, act, rest[0] if rest else None, ws, splits)
-        return dx, None, None, None, None, None, None
+        dx = K.gn_act_bwd(xc, dy, gamma, beta, groups, eps, act, film, ws, splits, pre)
+        return dx, None, None, None, None, None, None, None
 
 
-def group_norm_act(gn, x, act=True, film=None, act_fn=F.silu):
-    """GroupNorm `gn` (+ FiLM terms `film` = [B, 2C] scale | shift) (+ SiLU) of a score network.
+class _BiasAdd2(torch.autograd.Function):
+    """(h + bias_c) + other in one pass; the gradient reaches h and other unchanged."""
 
-    fp32 GPU tensors with frozen parameters -- the sampler's case -- run the fused HIP kernels (NHMC_FUSED_GN=0 keeps
-    the ATen sequence for A/B measurements); anything else (CPU tensors of the fixtures' side, float64 evaluation in the
-    parity tests, parameters that require grad) is plain torch, as for any other module of this file -- with `act_fn`
-    the activation in the reference's own form (nn.SiLU in the ADM U-Nets, x * sigmoid(x) in the VQ decoder)."""
-    hw = x[0, 0].numel()
-    if x.is_cuda and x.dtype == torch.float32 and hw % 4 == 0 and not (gn.weight.requires_grad or gn.bias.requires_grad) \
-            and (film is None or not film.requires_grad) and os.environ.get('NHMC_FUSED_GN', '1') != '0':
-        return _GroupNormAct.apply(x, gn.weight, gn.bias, film, gn.num_groups, gn.eps, act)
+    @staticmethod
+    def forward(ctx, h, bias, other):
+        return K.bias_add2(h if h.is_contiguous() else h.contiguous(), bias, other if other.is_contiguous() else other.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, g
+
+
+def fused_glue(x, *consts):
+    """True when the HIP glue kernels serve this call: fp32 GPU activations whose spatial size is a multiple of 4 and
+    constants (parameters, embedding terms) that carry no gradient; NHMC_FUSED_GN=0 keeps the ATen sequence (A/B runs)."""
+    return x.is_cuda and x.dtype == torch.float32 and x[0, 0].numel() % 4 == 0 and os.environ.get('NHMC_FUSED_GN', '1') != '0' \
+        and not any(c is not None and c.requires_grad for c in consts)
+
+
+def group_norm_act(gn, x, act=True, film=None, act_fn=F.silu, pre=None):
+    """GroupNorm `gn` of x (+ `pre`, a [C] or [B, C] term added first: the producing convolution's bias / an embedding
+    term) (+ FiLM terms `film` = [B, 2C] scale | shift) (+ SiLU) of a score network.
+
+    fp32 GPU tensors with frozen parameters -- the sampler's case -- run the fused HIP kernels; anything else (CPU
+    tensors of the fixtures' side, float64 evaluation in the parity tests, parameters that require grad) is plain torch,
+    as for any other module of this file -- with `act_fn` the activation in the reference's own form (nn.SiLU in the ADM
+    U-Nets, x * sigmoid(x) in the VQ decoder)."""
+    if fused_glue(x, gn.weight, gn.bias, film, pre):
+        return _GroupNormAct.apply(x, gn.weight, gn.bias, film, pre, gn.num_groups, gn.eps, act)
+    if pre is not None:
+        x = x + pre.reshape(((1, -1) if pre.dim() == 1 else tuple(pre.shape)) + (1,) * (x.dim() - 2))
     h = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
     if film is not None:
         scale, shift = film.reshape(film.shape + (1,) * (x.dim() - 2)).chunk(2, dim=1)
         h = h * (1 + scale) + shift
     return act_fn(h) if act else h
+
+
+def conv_nobias(conv, x):
+    """The convolution without its bias (the fused glue adds it where the output is consumed)."""
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 class Resample(nn.Module):
@@ -106,10 +133,14 @@ class ResBlock(nn.Module):
         h = group_norm_act(self.in_layers[0], x)                         # GroupNorm + SiLU
         if self.resample:
             h, x = self.h_upd(h), self.x_upd(x)
-        h = self.in_layers[2](h)
-        h = group_norm_act(self.out_layers[0], h, film=self.emb_layers(emb))   # scale-shift norm (FiLM) + SiLU
-        h = self.out_layers[3](h)
-        return self.skip_connection(x) + h
+        conv1, conv2, film = self.in_layers[2], self.out_layers[3], self.emb_layers(emb)
+        if fused_glue(h, conv1.bias, conv2.bias, film):
+            # the two convolutions run without their broadcast bias passes: conv1's bias enters the next GroupNorm's
+            # load, conv2's the residual add
+            h = group_norm_act(self.out_layers[0], conv_nobias(conv1, h), film=film, pre=conv1.bias)
+            return _BiasAdd2.apply(conv_nobias(conv2, h), conv2.bias, self.skip_connection(x))
+        h = group_norm_act(self.out_layers[0], conv1(h), film=film)      # scale-shift norm (FiLM) + SiLU
+        return self.skip_connection(x) + conv2(h)
 
 
 class AttentionBlock(nn.Module):

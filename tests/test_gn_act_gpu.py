@@ -74,3 +74,60 @@ def test_fallbacks_are_only_taken_where_documented():
     import nhmc._lib as L
     with pytest.raises(L.NhmcError):
         unet.K.gn_act_fwd(torch.randn(2, 64, 3, 3).cuda(), gn.weight, gn.bias, 32, 1e-5, 1)      # hw % 4 != 0 is refused, not emulated
+
+
+@pytest.mark.parametrize('per_sample', [False, True])
+def test_pre_bias_and_bias_residual_add(per_sample):
+    """The producing convolution's bias (and, in the LDM blocks, the embedding term) entering the GroupNorm's load, and a
+    convolution's bias folded into the residual add: same values and input gradients as the unfused torch sequence."""
+    from nhmc import unet
+    g = torch.Generator().manual_seed(5)
+    B, C, H = 3, 64, 16
+    gn = torch.nn.GroupNorm(32, C).cuda().requires_grad_(False)
+    gn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g).cuda())
+    gn.bias.copy_(0.1 * torch.randn(C, generator=g).cuda())
+    x = torch.randn(B, C, H, H, generator=g).cuda()
+    pre = (torch.randn(B, C, generator=g) if per_sample else torch.randn(C, generator=g)).cuda()
+    dy = torch.randn(B, C, H, H, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    ya = F.silu(F.group_norm(xa + pre.reshape(((1, -1) if pre.dim() == 1 else tuple(pre.shape)) + (1, 1)), 32, gn.weight, gn.bias, gn.eps))
+    (ga,) = torch.autograd.grad(ya, xa, dy)
+    xb = x.clone().requires_grad_(True)
+    yb = unet.group_norm_act(gn, xb, pre=pre)
+    assert type(yb.grad_fn).__name__.startswith('_GroupNormAct')
+    (gb,) = torch.autograd.grad(yb, xb, dy)
+    assert rel(yb, ya) < 2e-6 and rel(gb, ga) < 1e-5
+    # bias + residual add
+    h = torch.randn(B, C, H, H, generator=g).cuda().requires_grad_(True)
+    o = torch.randn(B, C, H, H, generator=g).cuda().requires_grad_(True)
+    bias = torch.randn(C, generator=g).cuda()
+    out = unet._BiasAdd2.apply(h, bias, o)
+    assert torch.equal(out, (h + bias[None, :, None, None]) + o)
+    gh, go = torch.autograd.grad(out, (h, o), dy)
+    assert torch.equal(gh, dy) and torch.equal(go, dy)
+
+
+def test_resblocks_with_and_without_the_fused_glue_agree():
+    """A ResBlock of each network family (FFHQ scale-shift block, LDM additive-embedding block, VQ decoder block):
+    fused glue vs NHMC_FUSED_GN=0, forward and input gradient."""
+    from nhmc import ldm, unet
+    torch.manual_seed(3)
+    blocks = [(unet.ResBlock(64, 128, 96), True), (unet.ResBlock(64, 128, 64, down=True), True),
+              (ldm.AddEmbResBlock(64, 128, 96), True), (ldm.PlainResBlock(64, 96), False)]
+    for blk, takes_emb in blocks:
+        blk = blk.cuda().eval().requires_grad_(False)
+        x = torch.randn(2, 64, 16, 16).cuda()
+        emb = torch.randn(2, 128).cuda()
+        dy = None
+        outs = []
+        for mode in ('1', '0'):
+            os.environ['NHMC_FUSED_GN'] = mode
+            try:
+                xl = x.clone().requires_grad_(True)
+                y = blk(xl, emb) if takes_emb else blk(xl)
+                dy = torch.randn_like(y) if dy is None else dy
+                (gx,) = torch.autograd.grad(y, xl, dy)
+                outs.append((y.detach(), gx))
+            finally:
+                os.environ.pop('NHMC_FUSED_GN')
+        assert rel(outs[0][0], outs[1][0]) < 5e-6 and rel(outs[0][1], outs[1][1]) < 2e-5, type(blk).__name__
