@@ -104,6 +104,29 @@ def conv_nobias(conv, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+class _Resample2x(torch.autograd.Function):
+    """2x2 average pool / nearest 2x upsample on the block-mean kernels of the SR operator (csrc/data_term.hip: `k_sr`
+    with ratio 2 is exactly this pair, H = block mean and H^T = broadcast x scale): each is the other's backward, so
+    ATen's slow avg_pool2d_backward (429 us per call at the U-Net's sizes) never runs."""
+
+    @staticmethod
+    def forward(ctx, x, up):
+        B, C, d = x.shape[0], x.shape[1], x.shape[2]
+        ctx.up, ctx.dims = up, (B, C, d)
+        xc = x if x.is_contiguous() else x.contiguous()
+        if up:
+            return K.sr_Ht(xc.reshape(B, -1), 2, C, 2 * d, 1.0).view(B, C, 2 * d, 2 * d)
+        return K.sr_H(xc, 2).view(B, C, d // 2, d // 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, d = ctx.dims
+        gc = g if g.is_contiguous() else g.contiguous()
+        if ctx.up:                                          # sum over each 2x2 block = 4 x its mean
+            return K.sr_H(gc, 2).view(B, C, d, d).mul_(4.0), None
+        return K.sr_Ht(gc.reshape(B, -1), 2, C, d, 0.25).view(B, C, d, d), None
+
+
 class Resample(nn.Module):
     """Parameter-free 2x nearest upsample / 2x2 average pool (the reference's conv-less up/down)."""
 
@@ -112,6 +135,9 @@ class Resample(nn.Module):
         self.up = up
 
     def forward(self, x):
+        if fused_glue(x) and x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[0] <= 65535 \
+                and (x.shape[2] % 8 == 0 or (self.up and x.shape[2] % 2 == 0)):
+            return _Resample2x.apply(x, self.up)
         return F.interpolate(x, scale_factor=2, mode='nearest') if self.up else F.avg_pool2d(x, 2)
 
 

@@ -131,3 +131,24 @@ def test_resblocks_with_and_without_the_fused_glue_agree():
             finally:
                 os.environ.pop('NHMC_FUSED_GN')
         assert rel(outs[0][0], outs[1][0]) < 5e-6 and rel(outs[0][1], outs[1][1]) < 2e-5, type(blk).__name__
+
+
+@pytest.mark.parametrize('up', [False, True])
+@pytest.mark.parametrize('shape', [(2, 32, 16, 16), (3, 8, 64, 64), (1, 4, 256, 256)])
+def test_resample_on_the_block_mean_kernels(up, shape):
+    """unet.Resample (2x2 average pool / nearest 2x upsample) on the SR operator's kernels = torch's ops, forward bit for
+    bit, backward too (each is the other's adjoint up to the factor 4)."""
+    from nhmc import unet
+    g = torch.Generator().manual_seed(shape[2] + up)
+    x = torch.randn(shape, generator=g).cuda()
+    r = unet.Resample(up)
+    xa = x.clone().requires_grad_(True)
+    ya = F.interpolate(xa, scale_factor=2, mode='nearest') if up else F.avg_pool2d(xa, 2)
+    dy = torch.randn(ya.shape, generator=g).cuda()
+    (ga,) = torch.autograd.grad(ya, xa, dy)
+    xb = x.clone().requires_grad_(True)
+    yb = r(xb)
+    assert type(yb.grad_fn).__name__.startswith('_Resample2x')
+    (gb,) = torch.autograd.grad(yb, xb, dy)
+    assert torch.equal(yb, ya) and rel(gb, ga) < 1e-6
+    assert not type(r(x.double().requires_grad_(True)).grad_fn).__name__.startswith('_Resample2x')     # float64 runs stay on torch
