@@ -233,3 +233,30 @@ def test_cli_runs_the_reference_command_line(tmp_path, monkeypatch, capsys):
     assert 'Total Average PSNR' in capsys.readouterr().out
     with pytest.raises(NotImplementedError):
         cli.main(['--dataset', 'tiny', '--algo', 'dps', '--deg', 'sr4', '--sigma_0', '0.05'])
+
+
+@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso'])
+def test_trajectory_does_not_depend_on_the_score_chunking(tiny_score, deg):
+    """`LeapfrogEngine.step` hands each score chunk's gradient pieces straight to that chunk's fused update (FIRST out of
+    place, then in place): chunked and unchunked trajectories are the same bits for a score without cross-sample ops,
+    and the caller's position is left untouched."""
+    from nhmc import sampler
+    dim, B, L = 32, 5, 4
+    g_ = gen(41)
+    missing = oops.random_inpaint_missing(dim, generator=g_)
+    ref, op = make_ops(deg, dim, missing)
+    x = torch.randn(B, 3, dim, dim, generator=g_).cuda()
+    p = torch.randn(B, 3, dim, dim, generator=g_).cuda()
+    y = (ref.H(torch.rand(B, 3, dim, dim, generator=g_) * 2 - 1) + 0.1 * torch.randn(B, ref.M, generator=g_)).cuda()
+    eps, sig = np.array([0.05, 0.04, 0.03, 0.0, 0.05]), np.array([1.7, 0.9, 0.1, 0.5, 1.0])     # chain 3 frozen (eps_eff = 0)
+    outs = []
+    for chunk in (None, 2, 3):
+        _, eng = engine_for(copy.deepcopy(tiny_score).cuda(), op, chunk=chunk)
+        x0 = x.clone()
+        got = sampler.run_trajectory(eng, x0, p.clone(), y, state_for(B, eps, sig), 1.0, L)
+        assert torch.equal(x0, x)                                              # accepted position untouched
+        outs.append({k: got[k].clone() for k in ('x_prop', 'p', 'xt', 'loss', 'H0', 'H1')})
+    for other in outs[1:]:
+        for k, v in outs[0].items():
+            assert torch.equal(v, other[k]) or rel(other[k], v) < 1e-6, k
+    assert torch.equal(outs[0]['x_prop'][3], x[3])                             # the frozen chain did not move
