@@ -159,7 +159,8 @@ def _report(rows, n_images, rank, world, device):
     table = sharding.gather_chains(local, n_images, rank, world).cpu()
     if rank == 0:
         for idx, mean, std in table.tolist():
-            print(f'image {int(idx)}: PSNR {mean:.3f} (std over samples {std:.4f})')
+            print(f'image {int(idx)}: PSNR {mean:.3f} (std over samples {std:.4f})' if mean == mean else
+                  f'image {int(idx)}: no sample was collected (every proposal of the final phase was rejected)')
         print(f'Total Average PSNR: {float(table[:, 1].nanmean()):.3f}  images: {table.shape[0]}')
     sharding.barrier()
     return table
