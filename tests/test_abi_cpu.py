@@ -66,6 +66,17 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.nhmc_spectral_apply(a16, a16, a16, a16, a16, a16, a16, a16, 1, 3, 48, null) == 3           # dim % 32
     assert lib.nhmc_sum_partials(a16, 4, 2, 2, 1, a16, null) == 1                                          # offset >= stride
     assert lib.nhmc_metropolis(null, a16, a16, null, a16, null, 1, null) == 1
+    # round-2 entry points
+    assert lib.nhmc_leapfrog_first(a16, a16, a16, a16, null, a16, a16, 1.0, 1, 1024, a16, null) == 1       # x_out aliases x_in
+    assert lib.nhmc_leapfrog_first(a16, P(0x2000), a16, a16, null, a16, a16, 1.0, 1, 1024, null, null) == 1  # needs sums_ws
+    assert lib.nhmc_vq_nearest(a16, a16, a16, null, 1, 5, 4096, 8192, null) == 3                           # embed_dim 5
+    assert lib.nhmc_vq_nearest(a16, null, a16, null, 1, 3, 4096, 8192, null) == 1
+    assert lib.nhmc_gn_act_fwd(a16, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, 1, 1, 64, 32, 9, null) == 3   # hw % 4
+    assert lib.nhmc_gn_act_fwd(a16, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, 1, 1, 48, 32, 64, null) == 3  # C % G
+    assert lib.nhmc_gn_act_bwd(a16, null, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, a16, 1, 1, 64, 32, 64, null) == 1
+    assert lib.nhmc_bias_add2(a16, a16, a16, a16, 1, 8, 6, null) == 3                                      # hw % 4
+    assert lib.nhmc_ddim_mix_bwd_inpaint_px(a16, a16, 6, a16, a16, a16, a16, a16, 10, a16, a16, 0, a16, 1, 3, 100, null) == 3  # hw % 32
+    assert lib.nhmc_inpaint_px_tiles(3, 65536) == 3 * 64 and lib.nhmc_gn_splits(32, 128, 32, 65536) >= 1
 
 
 def test_no_cpu_fallback_in_the_python_binding():
