@@ -24,7 +24,6 @@ Two behaviours of the reference that are easy to miss and are kept:
   * the first stage quantises on decode (`force_not_quantize=False`, ddpm.py:817): nearest codebook entry forward,
     straight-through gradient (taming-transformers 0.0.1, `VectorQuantizer2.forward`: z_q = z + (z_q - z).detach()).
 """
-import math
 
 import numpy as np
 import torch
