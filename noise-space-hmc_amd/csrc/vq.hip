@@ -8,14 +8,17 @@
 //     (the two norms are sequential fp32 sums, the inner product an FMA chain over c: torch's CPU kernels, bit for bit)
 //     z_q = z + (e_k* - z)            (the straight-through form: value of z + (z_q - z).detach())
 // torch materialises d as an [n_pixels, n_embed] fp32 matrix (4096 x 8192 x 4 B = 134 MB per chain, written once and
-// re-read by the argmin).  Here one thread owns one pixel and walks the codebook, which is staged through LDS in
-// chunks of VQ_CHUNK codes as (e_0..e_{D-1}, |e|^2): every lane of a wave reads the same LDS address (broadcast, no
-// bank conflicts), nothing but z, idx and z_q touches HBM (algorithmic bytes: 2T_z + 4 B per pixel).
+// re-read by the argmin).  Here the codebook is staged through LDS in chunks of VQ_CHUNK codes as (e_0..e_{D-1}, |e|^2)
+// and four lanes (one per wave of the block) share a pixel, each walking a quarter of every chunk: every lane of a wave
+// reads the same LDS address (broadcast, no bank conflicts), nothing but z, idx and z_q touches HBM (algorithmic bytes:
+// 2T_z + 4 B per pixel).
 #include "nhmc_common.h"
 
 namespace {
 
 constexpr int VQ_CHUNK = 2048;          // codes per LDS chunk: 2048 x 16 B = 32 KB (+8 KB of norms for D = 4)
+
+constexpr int VQ_PIX = 64;              // latent pixels per block: one per lane; the block's 4 waves split every codebook chunk
 
 template <int D>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
@@ -23,7 +26,13 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
     int32_t* __restrict__ idx_out, int64_t n_pix, int64_t hw, int n_embed) {
   __shared__ float4 code[VQ_CHUNK];
   __shared__ float norm[D == 4 ? VQ_CHUNK : 1];
-  const int64_t p = (int64_t)blockIdx.x * NHMC_BLOCK + threadIdx.x;
+  __shared__ float part_d[4][VQ_PIX];
+  __shared__ int part_k[4][VQ_PIX];
+  // 16 x 4096 latent pixels are only one wave per SIMD if a thread owns a pixel and walks the whole codebook (then VALU
+  // and LDS latencies are exposed: 247 us measured); so a pixel is shared by 4 lanes, one in each wave of the block, and
+  // wave w walks quarter w of every chunk -- 4 waves per SIMD, same broadcast LDS reads.
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t p = (int64_t)blockIdx.x * VQ_PIX + lane;
   const bool live = p < n_pix;
   const int64_t b = live ? p / hw : 0, pos = live ? p % hw : 0;
   const float* zp = z + b * D * hw + pos;
@@ -35,7 +44,8 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
     zz = c == 0 ? zc[0] * zc[0] : zz + zc[c] * zc[c];
   }
   float best = INFINITY;
-  int best_k = 0;
+  int best_k = 0x7fffffff;
+  constexpr int QUARTER = VQ_CHUNK / 4;
   for (int k0 = 0; k0 < n_embed; k0 += VQ_CHUNK) {
     __syncthreads();
     for (int k = threadIdx.x; k < VQ_CHUNK; k += NHMC_BLOCK) {
@@ -53,7 +63,8 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
     }
     __syncthreads();
 #pragma unroll 8
-    for (int k = 0; k < VQ_CHUNK; ++k) {
+    for (int kk = 0; kk < QUARTER; ++kk) {
+      const int k = part * QUARTER + kk;
       const float4 c4 = code[k];
       float dot = zc[0] * c4.x;                          // the -2 z.e term is a [n,D] x [D,n_embed] sgemm in the reference:
       dot = __fmaf_rn(zc[1], c4.y, dot);                 // a k-ordered FMA chain (bit-identical to torch's CPU sgemm,
@@ -61,10 +72,19 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
       float ee = c4.w;
       if constexpr (D == 4) { dot = __fmaf_rn(zc[3], c4.w, dot); ee = norm[k]; }
       const float d = (zz + ee) - 2.0f * dot;
-      if (d < best) { best = d; best_k = k0 + k; }
+      if (d < best) { best = d; best_k = k0 + k; }       // within a wave the code index only grows: first minimum kept
     }
   }
-  if (!live) return;
+  part_d[part][lane] = best;
+  part_k[part][lane] = best_k;
+  __syncthreads();
+  if (part != 0 || !live) return;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {                          // first minimum over the whole codebook: smallest d, then smallest index
+    const float d = part_d[w][lane];
+    const int k = part_k[w][lane];
+    if (d < best || (d == best && k < best_k)) { best = d; best_k = k; }
+  }
   if (idx_out) idx_out[p] = best_k;
   float* qp = z_q + b * D * hw + pos;
 #pragma unroll
@@ -81,7 +101,7 @@ extern "C" int nhmc_vq_nearest(const float* z, const float* codebook, float* z_q
   if (!z || !codebook || !z_q || n_chains <= 0 || hw <= 0 || n_embed <= 0) return NHMC_ERR_ARG;
   if (channels != 3 && channels != 4) return NHMC_ERR_SHAPE;
   const int64_t n_pix = (int64_t)n_chains * hw;
-  const dim3 grid((unsigned)((n_pix + NHMC_BLOCK - 1) / NHMC_BLOCK));
+  const dim3 grid((unsigned)((n_pix + VQ_PIX - 1) / VQ_PIX));
   if (channels == 3)
     NHMC_LAUNCH(k_vq_nearest<3>, grid, dim3(NHMC_BLOCK), 0, nhmc_s(stream), z, codebook, z_q, idx, n_pix, hw, n_embed);
   else
