@@ -140,6 +140,55 @@ def leapfrog_roofline(device, B, launches, n_elem=CH * DIM * DIM):
                 copy_note='nhmc_copy_probe: 1 read : 1 write streaming copy, same buffers; the update is 3 reads : 2 writes')
 
 
+def kernel_table(device, prob, B, launches=40):
+    """Every HIP kernel of one inpaint_random leapfrog step, timed alone with HIP events at the sampler's launch size
+    (B chains), rotating over buffer sets > the Infinity Cache: average launch time, algorithmic bytes,
+    fraction of the 8 TB/s peak.  The same kernels appear in profiles/rNN_kernel_stats_hip.csv (rocprofv3)."""
+    import nhmc.kernels as K
+    op = prob['op']
+    N = CH * DIM * DIM
+    T = N * 4 * B
+    R = 3
+    sets = [dict(x=K.randn_philox((B, CH, DIM, DIM), 11, 0, 5 * r, device=device),
+                 e=K.randn_philox((B, 2 * CH, DIM, DIM), 11, 0, 5 * r + 1, device=device),
+                 g=K.randn_philox((B, CH, DIM, DIM), 11, 0, 5 * r + 2, device=device),
+                 g2=K.randn_philox((B, CH, DIM, DIM), 11, 0, 5 * r + 3, device=device),
+                 p=K.randn_philox((B, CH, DIM, DIM), 11, 0, 5 * r + 4, device=device),
+                 ge=torch.zeros(B, 2 * CH, DIM, DIM, device=device)) for r in range(R)]
+    at = torch.full((B,), 0.0777966604, device=device)
+    an = torch.full((B,), 0.5214230418, device=device)
+    one = torch.ones(B, device=device)
+    eps = torch.full((B,), 1e-3, dtype=torch.float64, device=device)
+    sig = torch.full((B,), 1.7, dtype=torch.float64, device=device)
+    y = prob['y']
+    cases = [
+        ('k_mix_fwd (nhmc_ddim_mix_fwd)', 3 * T, lambda s: K.ddim_mix_fwd(s['x'], s['e'], at, an)),
+        ('k_mix_bwd, two upstream gradients (nhmc_ddim_mix_bwd)', 6 * T,
+         lambda s: K.ddim_mix_bwd(s['g'], s['x'], s['e'], at, an, gout2=s['g2'], g_e_out=s['ge'])),
+        ('data term + last-step VJP fused (operator.fused_last_vjp; incl. the 4 us partial-sum kernel)', 4 * T + int(op.M) * 4 * B,
+         lambda s: op.fused_last_vjp(s['x'], s['e'], an, one, y, g_e_out=s['ge'])),
+        ('k_leapfrog<MID>, second gradient pointer (nhmc_leapfrog_fused)', 6 * T,
+         lambda s: K.leapfrog_fused(K.LF_MID, s['x'], s['p'], s['g'], eps, sig, 1.0, g2=s['g2'])),
+    ]
+    rows = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, nbytes, fn in cases:
+        for r in range(R):
+            fn(sets[r])
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(launches):
+            fn(sets[i % R])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / launches
+        rows.append(dict(kernel=name, avg_us=round(us, 2), bytes_per_launch=nbytes, gbs=round(nbytes / us / 1e3, 1),
+                         frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)))
+    del sets
+    torch.cuda.empty_cache()
+    return rows
+
+
 class _ResidentScore(torch.autograd.Function):
     """Score stand-in for the hot-path leg: forward hands out a resident [B,2C,H,W] tensor, backward a resident
     input-gradient -- no arithmetic, so what is timed is exactly what the engine launches around the U-Net."""
@@ -498,6 +547,7 @@ def main():
     if rank == 0:
         roof = leapfrog_roofline(device, B, args.roofline_launches)
         hot = hot_path_only(device, prob, B, 20, chunk=args.chunk)
+        ktable = kernel_table(device, prob, B) if args.deg == 'inpaint_random' else None
         if in_situ:
             us = [a.elapsed_time(b_) * 1e3 for a, b_, _ in in_situ]
             chains = sum(n for _, _, n in in_situ) / len(in_situ)
@@ -536,7 +586,7 @@ def main():
                                    ('REHEARSAL with a 32-channel U-Net (not the metric)' if args.tiny_score else 'FFHQ U-Net architecture random-init fp32'),
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
-            'roofline': roofline, 'hot_path_only': hot, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
+            'roofline': roofline, 'hot_path_only': hot, 'hot_path_kernels': ktable, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
             'peak_memory_gib': round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1), 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
