@@ -339,9 +339,15 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_sr(
   constexpr int BPS = R >= 4 ? 1 : 4 / R;       // blocks per strip (R = 2 -> 2)
   const float inv = 1.0f / (float)(R * R);
 
-  float bs[BPS];
+  float bs[BPS], yv[BPS];
 #pragma unroll
-  for (int b = 0; b < BPS; ++b) bs[b] = 0.0f;
+  for (int b = 0; b < BPS; ++b) {
+    bs[b] = 0.0f;
+    // the observation of this thread's block(s): its address depends on indices only, so it is requested FIRST --
+    // loads return in issue order, and issued after the 2R streaming loads it would be waited for behind all of them
+    const int j = BPS == 1 ? (s * 4) / R : s * BPS + b;
+    yv[b] = live ? yplane[(int64_t)i * yd + j] : 0.0f;
+  }
   unsigned in_pre = 0u, in_u = 0u;              // bit rr*4+c: 1[-1 <= pre <= 1], 1[-1 <= u <= 1]   (R <= 8 rows per word)
   unsigned in_pre_hi = 0u, in_u_hi = 0u;        // rows 8..15 (R = 16)
   if (live) {
@@ -368,8 +374,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_sr(
   float acc = 0.0f, resid[BPS];
 #pragma unroll
   for (int b = 0; b < BPS; ++b) {
-    const int j = BPS == 1 ? (s * 4) / R : s * BPS + b;
-    resid[b] = live ? yplane[(int64_t)i * yd + j] - bs[b] * inv : 0.0f;
+    resid[b] = live ? yv[b] - bs[b] * inv : 0.0f;
     if (live && (LANES == 1 || (s % LANES) == 0)) acc += resid[b] * resid[b];
   }
   if (live) {
