@@ -258,10 +258,12 @@ def data_term_roofline(device, prob, B, launches=30):
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
     if hasattr(op, 'factors'):
-        flops = SPECTRAL_FLOP_PER_CHAIN * B
+        proj = bool(getattr(op, 'projected', False))                   # 4 products (residual in the left singular basis) instead of 8
+        flops = SPECTRAL_FLOP_PER_CHAIN * B // (2 if proj else 1)
         return dict(bound='mfma', achieved=round(flops / avg_s / 1e12, 1), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
                     frac=round(flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, avg_us=round(avg_s * 1e6, 1),
-                    kernel='spectral chain: data term + last-step VJP (nhmc_data_spectral_vjp), fp32 MFMA',
+                    kernel='spectral chain: data term + last-step VJP (%s), fp32 MFMA, %d products'
+                           % ('nhmc_data_spectral_proj_vjp' if proj else 'nhmc_data_spectral_vjp', 4 if proj else 8),
                     flops_per_call=flops, dtype='f32')
     T = CH * DIM * DIM * 4
     alg = (4 * T + op.M * 4) * B
@@ -401,9 +403,19 @@ def degradation_leg(device, deg, model, B, chunk, steps=2):
     ws = K.leapfrog_ws(B, CH * DIM * DIM, device)
     dt, _, _ = timed_steps(eng, prob['x'], prob['p'], prob['y'], eps, sig, ws, 1, steps, 1, 0, sharding, device)
     hot = hot_path_only(device, prob, B, 20, chunk=chunk)
-    return dict(value=round(B * steps / dt, 3), unit='chain-steps/s', steps=steps, ms_per_step=round(1e3 * dt / steps, 2),
-                hot_path_only=dict(value=round(hot['value'], 1), ms_per_step=round(hot['ms_per_step'], 4)),
-                roofline=data_term_roofline(device, prob, B), M=int(prob['op'].M), sigma_0=sigma0)
+    out = dict(value=round(B * steps / dt, 3), unit='chain-steps/s', steps=steps, ms_per_step=round(1e3 * dt / steps, 2),
+               hot_path_only=dict(value=round(hot['value'], 1), ms_per_step=round(hot['ms_per_step'], 4)),
+               roofline=data_term_roofline(device, prob, B), M=int(prob['op'].M), sigma_0=sigma0)
+    if hasattr(prob['op'], 'projected') and not prob['op'].projected:
+        # opt-in form (--spectral_projected): same operator, residual taken in the left singular basis
+        prob['op'].projected = True
+        try:
+            hot = hot_path_only(device, prob, B, 20, chunk=chunk)
+            out['spectral_projected'] = dict(hot_path_only=dict(value=round(hot['value'], 1), ms_per_step=round(hot['ms_per_step'], 4)),
+                                             roofline=data_term_roofline(device, prob, B))
+        finally:
+            prob['op'].projected = False
+    return out
 
 
 def latent_main(args):

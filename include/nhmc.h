@@ -236,6 +236,24 @@ int nhmc_data_spectral_vjp(const float* xt_next, const float* y, const float* fa
                            float* g_xt, float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
                            nhmc_stream_t stream);
 
+/* The same data term with the residual taken in the operator's left singular basis (U1, U2 orthogonal: full SVDs,
+ * Hfuncs.py:473-474):  y - H x = U1 (y^ - D o (V1^T x V2)) U2^T  with  y^ = U1^T y U2, so
+ *   |y - H x|^2 = |y^ - D o S|^2   and   H^T (y - H x) = V1 (D o (y^ - D o S)) V2^T      (S = V1^T x V2):
+ * four d^3 products per evaluation instead of eight.  y^ is constant over a run (main_sampling.py:694-695,710-711 use
+ * the same y_0 in every leapfrog step): compute it once with nhmc_spectral_project.
+ * nhmc_spectral_project      : out = L^T Y R per channel image (L = U1, R = U2 as stored); tmp: float[n_chains*C*d*d].
+ * nhmc_data_spectral_proj    : as nhmc_data_spectral with y_proj in place of y; tmp: float[n_chains*C*d*d].
+ * nhmc_data_spectral_proj_vjp: as nhmc_data_spectral_vjp with y_proj in place of y; same tmp. */
+int nhmc_spectral_project(const float* y, const float* L, const float* R, float* out, float* tmp, int n_chains,
+                          int channels, int dim, nhmc_stream_t stream);
+int nhmc_data_spectral_proj(const float* xt, const float* y_proj, const float* factors, const float* Dmap,
+                            int apply_clip, float* g_xt, double* loss_ws, float* tmp, int n_chains, int channels,
+                            int dim, nhmc_stream_t stream);
+int nhmc_data_spectral_proj_vjp(const float* xt_next, const float* y_proj, const float* factors, const float* Dmap,
+                                const float* xt, const float* e, int e_channels, const float* at,
+                                const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
+                                int n_chains, int channels, int dim, nhmc_stream_t stream);
+
 /* Separable strided convolution (SRConv / sr_bicubic, Hfuncs.py:527-607): H(X) = A X A^T, A [sd][d] the
  * (singular-value-truncated) 1-D kernel matrix; H^T(Y) = A^T Y A; H^+(Y) = A+ Y A+^T.  Same MFMA kernel, rectangular.
  * nhmc_sandwich_rect: t = in^T S1, out = t^T S2 with in [K1][R1], S1 [K1][C1], S2 [R1][C2] -> out [C1][C2] per image

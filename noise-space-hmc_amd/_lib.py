@@ -51,6 +51,9 @@ SIGNATURES = {
     'nhmc_spectral_tiles': (I, [I, I]),
     'nhmc_data_spectral': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
     'nhmc_data_spectral_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
+    'nhmc_spectral_project': (I, [P, P, P, P, P, I, I, I, P]),
+    'nhmc_data_spectral_proj': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
+    'nhmc_data_spectral_proj_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
     'nhmc_sandwich_rect': (I, [P, P, P, P, P, I, I, I, I, I, P]),
     'nhmc_srconv_tiles': (I, [I, I]),
     'nhmc_data_srconv': (I, [P, P, P, P, I, P, P, P, I, I, I, I, P]),

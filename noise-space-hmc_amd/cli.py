@@ -12,7 +12,9 @@ sampled in parallel as independent chains (the reference is batch-1), `--score_c
 shard-invariant counter-based generator.  Under torchrun the images are sharded over ranks and the per-image
 metrics are gathered once at the end (RCCL).  The measurement noise and the start point of image s are drawn from a
 generator keyed by (seed, s) -- never from the global stream -- so with `--philox` (implied when WORLD_SIZE > 1) an
-image's result does not depend on the number of ranks or on `--chains`.
+image's result does not depend on the number of ranks (nor, up to the score network's batch-size-dependent
+convolution rounding, on `--chains`).  `--spectral_projected` switches the two blur operators to the four-product data
+term (operators.Deblurring2D).
 """
 import argparse
 import glob
@@ -58,6 +60,8 @@ def get_parser(latent=False):
     p.add_argument('--synthetic', type=int, default=0, help='use this many synthetic images')
     p.add_argument('--philox', action='store_true', help='counter-based, shard-invariant noise')
     p.add_argument('--save_images', action='store_true')
+    p.add_argument('--spectral_projected', action='store_true',
+                   help='deblur_aniso / deblur_gauss: residual in the left singular basis, 4 products instead of 8 (rounds differently)')
     p.add_argument('--graph', dest='use_graph', action='store_true',
                    help='replay each decode+gradient chunk as a hipGraph (helps single-chain runs: ~1.2x)')
     p.add_argument('--hmc_epochs', type=int, default=60, help='annealing epochs (reference: 60, main_sampling.py:665)')
@@ -150,7 +154,8 @@ def _setup(opt, latent):
     np.random.seed(opt.seed)
     random.seed(opt.seed)
     size, ch = config['data']['image_size'], config['data']['channels']
-    op = operators.build_operator(opt.deg, ch, size, device)               # mask = first torch RNG draw, as in the reference
+    # mask = first torch RNG draw, as in the reference
+    op = operators.build_operator(opt.deg, ch, size, device, spectral_projected=opt.spectral_projected or None)
     opt.sigma_0 = 2 * opt.sigma_0                                           # [-1,1] scaling, main_sampling.py:348
     if world > 1 and not opt.philox:
         if rank == 0:

@@ -27,7 +27,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4 };
+enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4, EPI_SRES = 5 };
+// EPI_SRES: the residual taken in the operator's left singular basis: r^ = y^ - D o acc with y^ = U1^T y U2 (aux), loss
+// partial += r^2, out = D o r^ -- the input of the adjoint's last two products (see nhmc_data_spectral_proj).
 // EPI_VJP: the gradient tile goes straight through the VJP of the last DDIM step (k_mix_bwd, final clip included)
 struct VjpArgs { const float* e; float* g_e; const float* at; const float* at_next; int e_channels; };
 constexpr int BK = 32;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
   static_assert((T / NW) * T <= 2 * BK * T, "accumulator slab must fit the operand tiles");
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * R * C;
-  const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * R * C : nullptr;
+  const float* __restrict__ dm_img = (EPI == EPI_MULD || EPI == EPI_SRES) ? Dmap + (int64_t)c * R * C : nullptr;
   const float* __restrict__ aux_img = aux ? aux + (int64_t)img * R * C : nullptr;
   float lsum = 0.0f;
   // EPI_VJP: aux = the DDIM step's input xt; e / g_e are [chain][e_channels][R][C]
@@ -148,6 +150,13 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
         q = yv - q;                                       // r = y - H x
         lsum += q.x * q.x; lsum += q.y * q.y; lsum += q.z * q.z; lsum += q.w * q.w;
       }
+      if (EPI == EPI_SRES) {
+        const nhmc_v4f d = *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
+        const nhmc_v4f yv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+        q = yv - q * d;                                   // r^ = U1^T (y - H x) U2
+        lsum += q.x * q.x; lsum += q.y * q.y; lsum += q.z * q.z; lsum += q.w * q.w;
+        q = q * d;
+      }
       if (EPI == EPI_GRAD) {
         q = -(2.0f * q);
         if (aux_img) {
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
     }
     __syncthreads();                                      // the slab is rewritten by the next row of waves
   }
-  if (EPI == EPI_RESID) {
+  if (EPI == EPI_RESID || EPI == EPI_SRES) {
     __shared__ double red[NW * NW];
     double sw = nhmc_wave_sum((double)lsum);
     if (lane == 0) red[wave] = sw;
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
   __syncthreads();
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * D * D;
-  const float* __restrict__ dm_img = (EPI == EPI_MULD) ? Dmap + (int64_t)c * D * D : nullptr;
+  const float* __restrict__ dm_img = (EPI == EPI_MULD || EPI == EPI_SRES) ? Dmap + (int64_t)c * D * D : nullptr;
   const float* __restrict__ aux_img = aux ? aux + (int64_t)img * D * D : nullptr;
   const float* __restrict__ e_img = nullptr;
   float* __restrict__ ge_img = nullptr;
@@ -351,6 +360,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
     if (EPI == EPI_RESID) {
       o = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]) - o;                   // r = y - H x
       lsum += o.x * o.x; lsum += o.y * o.y; lsum += o.z * o.z; lsum += o.w * o.w;
+    }
+    if (EPI == EPI_SRES) {
+      const nhmc_v4f d = *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
+      o = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]) - o * d;             // r^ = U1^T (y - H x) U2
+      lsum += o.x * o.x; lsum += o.y * o.y; lsum += o.z * o.z; lsum += o.w * o.w;
+      o = o * d;
     }
     if (EPI == EPI_GRAD) {
       o = -(2.0f * o);
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
     }
     *reinterpret_cast<nhmc_v4f*>(&out_img[off]) = o;
   }
-  if (EPI == EPI_RESID) {
+  if (EPI == EPI_RESID || EPI == EPI_SRES) {
     __shared__ double red[NW];
     double sw = nhmc_wave_sum((double)lsum);
     if (lane == 0) red[wave] = sw;
@@ -556,6 +571,86 @@ extern "C" int nhmc_data_spectral_vjp(const float* xt_next, const float* y, cons
   if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
   const VjpArgs vj{e, g_e, at, at_next, e_channels};
   return gemm<EPI_VJP, false>(A, V2T, g_xt, nullptr, xt, nullptr, n, channels, dim, st, vj);
+}
+
+// ---- the data term with the residual taken in the left singular basis ------------------------------------------------
+// U1, U2 are orthogonal (full SVDs, Hfuncs.py:473-474), so with y^ = U1^T y U2 (constant over a run: one sandwich when
+// the observation is set)
+//     y - H x = U1 (y^ - D o S) U2^T,   S = V1^T x V2      =>   |y - H x|^2 = |y^ - D o S|^2,
+//     H^T (y - H x) = V1 (D o (y^ - D o S)) V2^T,
+// the two products by U^T and the two by U of the chain above cancel: FOUR products per evaluation instead of eight,
+// one intermediate instead of three.  Not the reference's rounding sequence: against the reference's operator evaluated
+// in fp64 the gradient moves by 3-7e-6 relative (the factors' 1e-6 departure from orthogonality times |H x| / |r|; the
+// reference's own fp32 evaluation sits 1-2e-6 from the same fp64 value), the loss by 1e-7 -- inside the 1e-4 contract
+// (tests/test_spectral_proj_gpu.py measures both against the eight-product form).
+extern "C" int nhmc_spectral_project(const float* y, const float* L, const float* R, float* out, float* tmp, int n_chains,
+                                     int channels, int dim, nhmc_stream_t stream) {
+  if (!y || !L || !R || !out || !tmp) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(y) || !nhmc_aligned16(L) || !nhmc_aligned16(R) || !nhmc_aligned16(out) || !nhmc_aligned16(tmp))
+    return NHMC_ERR_ALIGN;
+  hipStream_t st = nhmc_s(stream);
+  const int n = n_chains * channels;
+  if (dim == 256 && pairs_enabled()) return pair256<EPI_NONE, false>(y, L, R, out, nullptr, nullptr, nullptr, n, channels, st);
+  int rc;
+  if ((rc = gemm<EPI_NONE, false>(y, L, tmp, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;       // Y^T L
+  return gemm<EPI_NONE, false>(tmp, R, out, nullptr, nullptr, nullptr, n, channels, dim, st);                    // L^T Y R
+}
+
+namespace {
+// shared body: `vjp` == nullptr -> EPI_GRAD (mask from `clip_src` when given), else the last DDIM step's VJP epilogue
+int data_spectral_proj(const float* x_in, bool preclip, const float* y_proj, const float* factors, const float* Dmap,
+                       const float* mask_or_xt, const VjpArgs* vjp, float* g_xt, double* loss_ws, float* tmp, int n,
+                       int channels, int dim, hipStream_t st) {
+  const int64_t dd = (int64_t)dim * dim;
+  const float *V1 = factors + 2 * dd, *V2 = factors + 3 * dd, *V1T = factors + 6 * dd, *V2T = factors + 7 * dd;
+  float* A = tmp;
+  float* B = g_xt;                                          // free until the last product writes it
+  int rc;
+  if (dim == 256 && pairs_enabled()) {
+    if (preclip) { if ((rc = pair256<EPI_SRES, true>(x_in, V1, V2, A, Dmap, y_proj, loss_ws, n, channels, st))) return rc; }
+    else         { if ((rc = pair256<EPI_SRES, false>(x_in, V1, V2, A, Dmap, y_proj, loss_ws, n, channels, st))) return rc; }
+    if (vjp) return pair256<EPI_VJP, false>(A, V1T, V2T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, st, *vjp);
+    return pair256<EPI_GRAD, false>(A, V1T, V2T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, st);
+  }
+  if (preclip) { if ((rc = gemm<EPI_NONE, true>(x_in, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
+  else         { if ((rc = gemm<EPI_NONE, false>(x_in, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
+  if ((rc = gemm<EPI_SRES, false>(A, V2, B, Dmap, y_proj, loss_ws, n, channels, dim, st))) return rc;
+  if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
+  if (vjp) return gemm<EPI_VJP, false>(A, V2T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, dim, st, *vjp);
+  return gemm<EPI_GRAD, false>(A, V2T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, dim, st);
+}
+}  // namespace
+
+// nhmc_data_spectral with y_proj = U1^T y U2 (nhmc_spectral_project(y, U1, U2)) in place of y.  tmp: float[n*C*d*d]
+// (the one-product-per-launch form parks its second intermediate in g_xt).
+extern "C" int nhmc_data_spectral_proj(const float* xt, const float* y_proj, const float* factors, const float* Dmap,
+                                       int apply_clip, float* g_xt, double* loss_ws, float* tmp, int n_chains,
+                                       int channels, int dim, nhmc_stream_t stream) {
+  if (!xt || !y_proj || !factors || !Dmap || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y_proj) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(tmp) || !nhmc_aligned16(Dmap))
+    return NHMC_ERR_ALIGN;
+  return data_spectral_proj(xt, apply_clip != 0, y_proj, factors, Dmap, apply_clip ? xt : nullptr, nullptr, g_xt, loss_ws,
+                            tmp, n_chains * channels, channels, dim, nhmc_s(stream));
+}
+
+// nhmc_data_spectral_vjp with y_proj in place of y.
+extern "C" int nhmc_data_spectral_proj_vjp(const float* xt_next, const float* y_proj, const float* factors,
+                                           const float* Dmap, const float* xt, const float* e, int e_channels,
+                                           const float* at, const float* at_next, float* g_xt, float* g_e,
+                                           double* loss_ws, float* tmp, int n_chains, int channels, int dim,
+                                           nhmc_stream_t stream) {
+  if (!xt_next || !y_proj || !factors || !Dmap || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
+    return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim) || (e_channels != channels && e_channels != 2 * channels)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y_proj) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(tmp) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_e) || !nhmc_aligned16(Dmap))
+    return NHMC_ERR_ALIGN;
+  const VjpArgs vjp{e, g_e, at, at_next, e_channels};
+  return data_spectral_proj(xt_next, false, y_proj, factors, Dmap, xt, &vjp, g_xt, loss_ws, tmp, n_chains * channels,
+                            channels, dim, nhmc_s(stream));
 }
 
 // ---- separable strided convolution (SRConv, obs_functions/Hfuncs.py:527-607) ----------------------------------

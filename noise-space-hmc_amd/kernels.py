@@ -447,34 +447,47 @@ def data_srconv_vjp(xt_next, y, At, A, xt, e, at, at_next, g_e_out=None, loss_ou
     return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
 
-def data_spectral(xt, y, factors, Dmap, apply_clip=True, loss_out=None):
-    """factors: packed [8,d,d] = U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T -> (loss [B] float64, g_xt)"""
+def spectral_project(y, L, R):
+    """y^ = L^T Y R per channel image (L = U1, R = U2): the observation in the operator's left singular basis."""
+    lib = _lib.load()
+    B, Cc, dim = y.shape[0], y.shape[1], y.shape[2]
+    out, tmp = torch.empty_like(y), torch.empty_like(y)
+    rc = lib.nhmc_spectral_project(_p(y, torch.float32, 'y'), _p(L, torch.float32), _p(R, torch.float32), _p(out), _p(tmp),
+                                   B, Cc, dim, _stream())
+    _lib.check(rc, 'nhmc_spectral_project')
+    return out
+
+
+def data_spectral(xt, y, factors, Dmap, apply_clip=True, loss_out=None, projected=False):
+    """factors: packed [8,d,d] = U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T -> (loss [B] float64, g_xt).
+    projected: `y` is spectral_project(y, U1, U2) and the four-product form runs."""
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
     tiles = lib.nhmc_spectral_tiles(Cc, dim)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
-    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    tmp = torch.empty((1 if projected else 2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
     g = torch.empty_like(xt)
-    rc = lib.nhmc_data_spectral(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'),
-                                _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32), int(apply_clip),
-                                _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    fn = lib.nhmc_data_spectral_proj if projected else lib.nhmc_data_spectral
+    rc = fn(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(factors, torch.float32, 'factors'),
+            _p(Dmap, torch.float32), int(apply_clip), _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_spectral')
     return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None, loss_out=None):
+def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None, loss_out=None, projected=False):
     """Spectral data term on the clipped decode `xt_next` + VJP of the last DDIM step (inputs xt, e) in the last
-    product's epilogue -> (loss [B] float64, g_xt, g_e)."""
+    product's epilogue -> (loss [B] float64, g_xt, g_e).  projected: as in data_spectral."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     dim = xt.shape[2]
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     tiles = lib.nhmc_spectral_tiles(Cc, dim)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
-    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    tmp = torch.empty((1 if projected else 2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)          # channels [0, C) are written
-    rc = lib.nhmc_data_spectral_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'),
+    fn = lib.nhmc_data_spectral_proj_vjp if projected else lib.nhmc_data_spectral_vjp
+    rc = fn(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'),
                                     _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32),
                                     _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                     _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())

@@ -11,6 +11,7 @@ Operator constants (index maps, factor matrices) are built once on the host -- O
 reference's O(N*M) Python list comprehension (Hfuncs.py:125) -- and stay resident on the device.
 """
 import math
+import os
 
 import torch
 
@@ -156,7 +157,7 @@ class Deblurring2D(H_functions):
     `from_factors` takes exported operator data (a reference instance built elsewhere, e.g. on its GPU).
     """
 
-    def __init__(self, kernel1, kernel2, channels, img_dim, device, zero=3e-2):
+    def __init__(self, kernel1, kernel2, channels, img_dim, device, zero=3e-2, projected=None):
         H1, H2 = _band_matrix(kernel1.detach().cpu().float(), img_dim), _band_matrix(kernel2.detach().cpu().float(), img_dim)
         U1, s1, V1 = torch.svd(H1, some=False)
         U2, s2, V2 = torch.svd(H2, some=False)
@@ -169,15 +170,15 @@ class Deblurring2D(H_functions):
         D = torch.zeros(channels, hw)
         for c in range(channels):
             D[c, perm] = s_sorted[(channels * k + c) % hw]
-        self._init_factors(U1, U2, V1, V2, D.reshape(channels, img_dim, img_dim), device)
+        self._init_factors(U1, U2, V1, V2, D.reshape(channels, img_dim, img_dim), device, projected)
 
     @classmethod
-    def from_factors(cls, U1, U2, V1, V2, D, device):
+    def from_factors(cls, U1, U2, V1, V2, D, device, projected=None):
         self = cls.__new__(cls)
-        self._init_factors(U1, U2, V1, V2, D, device)
+        self._init_factors(U1, U2, V1, V2, D, device, projected)
         return self
 
-    def _init_factors(self, U1, U2, V1, V2, D, device):
+    def _init_factors(self, U1, U2, V1, V2, D, device, projected=None):
         self.channels, self.img_dim = D.shape[0], D.shape[1]
         if self.img_dim % 32:
             raise NhmcError('spectral operator needs img_dim % 32 == 0')
@@ -188,6 +189,20 @@ class Deblurring2D(H_functions):
         self.Dmap = D.detach().cpu().float().contiguous().to(device)
         Dp = torch.where(self.Dmap != 0, 1.0 / self.Dmap, torch.zeros_like(self.Dmap))
         self.Dpinv = Dp.contiguous()
+        # Opt-in (projected=True / NHMC_SPECTRAL_PROJECTED=1 / --spectral_projected): the data term takes the residual
+        # in the left singular basis -- four products instead of eight (nhmc_data_spectral_proj), valid when U1, U2 are
+        # orthogonal to fp32 accuracy, which full SVDs are.  The default stays the reference's eight-product rounding
+        # sequence: the projected gradient sits 3-7e-6 from it, and over a long run that is enough to flip a clip-mask
+        # bit the reference did not (tests/test_spectral_proj_gpu.py: the G14 replay follows the reference's energies
+        # to 5e-4 for 129 trajectories, then departs).
+        eye = torch.eye(self.img_dim)
+        self.orthogonality_error = max(float((m.t() @ m - eye).abs().max()) for m in mats[:2])
+        if projected is None:
+            projected = os.environ.get('NHMC_SPECTRAL_PROJECTED', '0') == '1'
+        if projected and self.orthogonality_error >= 1e-5:
+            raise NhmcError(f'projected spectral data term needs orthogonal U factors (|U^T U - I| = {self.orthogonality_error:.1e})')
+        self.projected = bool(projected)
+        self._y_proj = {}
 
     def _f(self, i):
         return self.factors[i]
@@ -205,8 +220,28 @@ class Deblurring2D(H_functions):
         y = _img(vec, self.channels, self.img_dim)
         return K.spectral_apply(y, self._f(0), self._f(1), self.Dpinv, self._f(6), self._f(7)).reshape(y.shape[0], -1)
 
+    def project_observation(self, y):
+        """y^ = U1^T y U2, cached per observation buffer: the sampler passes the same y_0 (or the same chunk views of it)
+        in every leapfrog step of a run.  An entry pins the buffer's storage, so its address cannot be handed to another
+        tensor while the entry lives; an in-place write bumps the version and misses."""
+        key = (y.data_ptr(), y._version, tuple(y.shape))
+        hit = self._y_proj.get(key)
+        if hit is None:
+            if len(self._y_proj) >= 16:
+                self._y_proj.pop(next(iter(self._y_proj)))
+            hit = (K.spectral_project(y, self._f(0), self._f(1)), y.untyped_storage())
+            self._y_proj[key] = hit
+        return hit[0]
+
+    def _obs(self, y, shape):
+        y = y.reshape(shape)
+        if not y.is_contiguous():
+            y = y.contiguous()
+        return self.project_observation(y) if self.projected else y
+
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
-        return K.data_spectral(xt, y.reshape(xt.shape).contiguous(), self.factors, self.Dmap, apply_clip, loss_out=loss_out)
+        return K.data_spectral(xt, self._obs(y, xt.shape), self.factors, self.Dmap, apply_clip, loss_out=loss_out,
+                               projected=self.projected)
 
     fused_wants_decode = True              # the engine hands over the clipped decode it already holds
 
@@ -215,16 +250,16 @@ class Deblurring2D(H_functions):
         xt_next: the clipped decode of that step (recomputed when the caller does not have it)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
-        return K.data_spectral_vjp(xt_next, y.reshape(xt_in.shape).contiguous(), self.factors, self.Dmap, xt_in, e, at,
-                                   at_next, g_e_out=g_e_out, loss_out=loss_out)
+        return K.data_spectral_vjp(xt_next, self._obs(y, xt_in.shape), self.factors, self.Dmap, xt_in, e, at,
+                                   at_next, g_e_out=g_e_out, loss_out=loss_out, projected=self.projected)
 
 
 class Deblurring(Deblurring2D):
     """obs_functions/Hfuncs.py:236-316 (`deblur_gauss`): the same spectral form with one 1-D kernel on both
     axes -- and the same tiled-singulars / interleaved-Vt multiplier layout (:308-309 vs :265-271)."""
 
-    def __init__(self, kernel, channels, img_dim, device, ZERO=3e-2):
-        super().__init__(kernel, kernel, channels, img_dim, device, zero=ZERO)
+    def __init__(self, kernel, channels, img_dim, device, ZERO=3e-2, projected=None):
+        super().__init__(kernel, kernel, channels, img_dim, device, zero=ZERO, projected=projected)
 
 
 class Colorization(H_functions):
@@ -374,8 +409,9 @@ def gaussian_taps(sigma, half=4):
     return k / k.sum()
 
 
-def build_operator(deg, channels, img_dim, device, generator=None):
-    """`prepare_measurement` (main_sampling.py:261-351) for the degradations on the HMC hot path."""
+def build_operator(deg, channels, img_dim, device, generator=None, spectral_projected=None):
+    """`prepare_measurement` (main_sampling.py:261-351) for the degradations on the HMC hot path.
+    spectral_projected: the four-product data term of the two blur operators (see Deblurring2D)."""
     if deg.startswith('sr_bicubic') and deg[10:].isdigit():
         factor = int(deg[10:])
         return SRConv(bicubic_taps(factor), channels, img_dim, device, stride=factor)
@@ -392,9 +428,9 @@ def build_operator(deg, channels, img_dim, device, generator=None):
         missing[left:left + 128, up:up + 128, :] = 1.0
         return Inpainting(channels, img_dim, torch.nonzero(missing.view(-1)).squeeze(1), device)
     if deg == 'deblur_aniso':
-        return Deblurring2D(gaussian_taps(1.0), gaussian_taps(20.0), channels, img_dim, device)
+        return Deblurring2D(gaussian_taps(1.0), gaussian_taps(20.0), channels, img_dim, device, projected=spectral_projected)
     if deg == 'deblur_gauss':
-        return Deblurring(gaussian_taps(10.0, half=2), channels, img_dim, device)           # main_sampling.py:308-314
+        return Deblurring(gaussian_taps(10.0, half=2), channels, img_dim, device, projected=spectral_projected)  # main_sampling.py:308-314
     if deg == 'color':
         return Colorization(img_dim, device)
     if deg.startswith('cs') and deg[2:].isdigit():

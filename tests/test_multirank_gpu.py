@@ -45,7 +45,9 @@ def test_cli_results_do_not_depend_on_the_number_of_ranks(tmp_path):
     args = ['--dataset', 'tiny', '--algo', 'hmc', '--timesteps', '3', '--deg', 'sr4', '--sigma_0', '0.05', '-i', str(tmp_path / 'out'),
             '--tau', '0.1', '--epsilon', '0.05', '--synthetic', '4', '--philox', '--hmc_epochs', '3', '--hmc_sampling', '2']
     script = os.path.join(ROOT, 'main_sampling.py')
-    one = subprocess.run([sys.executable, script] + args + ['--chains', '4'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    # the same per-process batch composition on both sides (one image at a time): a different batch size may pick
+    # another MIOpen convolution solver, whose 1e-6 rounding differences can flip an accept decision of the fp32 run
+    one = subprocess.run([sys.executable, script] + args + ['--chains', '1'], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = _torchrun(2, script, args + ['--chains', '1'], tmp_path)
     assert two.returncode == 0, two.stderr[-2000:]

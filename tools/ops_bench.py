@@ -17,10 +17,11 @@ T = B * 3 * 256 * 256 * 4
 op = operators.build_operator('deblur_aniso', 3, 256, dev)
 y = K.randn_philox((B, 3, 256, 256), 1, 0, 1).reshape(B, -1)
 ms = timeit(lambda: op.data_term(x, y, True), 10)
-fl = 8 * B * 3 * 2 * 256 ** 3
-print(f'aniso data term B={B}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)')
+nprod = 4 if op.projected else 8
+fl = nprod * B * 3 * 2 * 256 ** 3
+print(f'aniso data term B={B}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP executed, {nprod} products)')
 ms = timeit(lambda: op.H(x), 10)
-print(f'aniso H B={B}: {ms:.3f} ms  {fl/2/ms/1e9:.1f} TFLOP/s')
+print(f'aniso H B={B}: {ms:.3f} ms  {4 * B * 3 * 2 * 256 ** 3/ms/1e9:.1f} TFLOP/s')
 op4 = operators.build_operator('sr4', 3, 256, dev)
 y4 = torch.randn(B, op4.M, device=dev)
 ms = timeit(lambda: op4.data_term(x, y4, True))
