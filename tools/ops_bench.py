@@ -54,3 +54,8 @@ def two_kernel():
 ms2 = timeit(two_kernel, 10)
 ms1 = timeit(lambda: op.fused_last_vjp(x, e6, at, an, y, g_e_out=ge, xt_next=cur), 10)
 print(f'aniso data term + last VJP B={B}: two kernels {ms2*1e3:.1f} us, fused epilogue {ms1*1e3:.1f} us')
+opp = operators.build_operator('deblur_aniso', 3, 256, dev, spectral_projected=True)
+ms = timeit(lambda: opp.data_term(x, y, True), 10)
+msv = timeit(lambda: opp.fused_last_vjp(x, e6, at, an, y, g_e_out=ge, xt_next=cur), 10)
+flp = 4 * B * 3 * 2 * 256 ** 3
+print(f'aniso projected (4 products) B={B}: data term {ms*1e3:.1f} us {flp/ms/1e9:.1f} TFLOP/s, + last VJP {msv*1e3:.1f} us {flp/msv/1e9:.1f} TFLOP/s')
