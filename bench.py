@@ -356,19 +356,51 @@ def single_chain_rate(eng, x, p, y, eps, sig, with_graph):
                 reference_derived=3.2, note='reference: >= 2100 leapfrog decodes per image / 663 s (BASELINE.md), unstated GPU')
 
 
+def settle_score_chunk(eng, make_engine, args, step, world, rank, sharding, device):
+    """One untimed step on every rank before the contract's warm-up, for two reasons.  (i) The first score-network call on
+    a machine fills MIOpen's on-disk kernel cache (~1 min): rank 0 goes first, alone, instead of N ranks racing through the
+    same compiles and cache files.  (ii) If the step does not fit the card on ANY rank, every rank halves its score chunk
+    together (a collective decision, so the ranks stay in step) and tries again."""
+    import gc
+    while True:
+        failed = [0.0]
+
+        def probe():
+            try:
+                if os.environ.get('NHMC_BENCH_FAKE_OOM') == str(rank) and not getattr(args, 'faked_oom', False):
+                    args.faked_oom = True                                  # test hook: tests/test_multirank_gpu.py
+                    raise torch.OutOfMemoryError('NHMC_BENCH_FAKE_OOM')
+                step(eng)
+                torch.cuda.synchronize()
+            except torch.OutOfMemoryError:
+                failed[0] = 1.0
+        if world > 1:
+            if rank == 0:
+                probe()
+            sharding.barrier()
+            if rank != 0:
+                probe()
+        else:
+            probe()
+        if not sharding.max_over_ranks(failed[0], device):
+            return eng
+        if args.chunk <= 1:
+            raise SystemExit('[bench] one chain per score call does not fit this card')
+        eng = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        args.chunk = (args.chunk + 1) // 2
+        if rank == 0:
+            print(f'[bench] out of memory at one score chunk; every rank retries with --chunk {args.chunk}', file=sys.stderr, flush=True)
+        eng = make_engine(args.chunk)
+
+
 def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding, device):
     """The contract's timed region: W untimed steps, barrier + synchronize, K steps, synchronize + barrier, max over ranks."""
     import nhmc.kernels as K
 
     def step():
         return eng.step(K.LF_MID, x, x, p, y, eps, sig, 1.0, ws)
-    if world > 1:
-        # the first score-network call on a machine fills MIOpen's on-disk kernel cache (~1 min); let one rank do it
-        # instead of N ranks racing through the same compiles and the same cache files
-        if rank == 0:
-            step()
-            torch.cuda.synchronize()
-        sharding.barrier()
     for _ in range(warmup):
         step()
     sharding.barrier()
@@ -450,6 +482,10 @@ def latent_main(args):
     eps = torch.full((B,), 0.1, dtype=torch.float64, device=device)            # main_sampling_latent.py:828-830 default
     sig = torch.full((B,), 0.5, dtype=torch.float64, device=device)            # --sigma_y default, :832
     ws = K.leapfrog_ws(B, x[0].numel(), device)
+    args.chunk = args.chunk or B
+    eng = settle_score_chunk(eng, lambda c: sampler.LeapfrogEngine(algo.score, op, None, seq, seq_next, device, chunk=c, alpha_table=table,
+                                                                  image_map=model.differentiable_decode_first_stage),
+                             args, lambda e: e.step(K.LF_MID, x, x, p, y, eps, sig, 1.0, ws), world, rank, sharding, device)
     dt, loss, _ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
     stats = torch.stack([loss.float(), x.reshape(B, -1).pow(2).sum(1)], dim=1).contiguous()
     allstats = sharding.gather_chains(stats, world * B, rank, world)
@@ -532,18 +568,10 @@ def main():
     ms_per_step = value = gather = None
     in_situ = []
     if not args.kernel_only:
-        try:
-            dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
-        except torch.OutOfMemoryError:
-            if world > 1:
-                raise                                               # ranks must stay in step: rerun with --chunk 32
-            eng = None
-            torch.cuda.empty_cache()
-            args.chunk = (args.chunk + 1) // 2
-            print(f'[bench] out of memory at one score chunk; retrying with --chunk {args.chunk}', file=sys.stderr, flush=True)
-            eng = sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'], prob['seq_next'], device,
-                                         chunk=args.chunk)
-            dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
+        eng = settle_score_chunk(eng, lambda c: sampler.LeapfrogEngine(prob['algo'].score, prob['op'], prob['b'], prob['seq'],
+                                                                      prob['seq_next'], device, chunk=c),
+                                 args, lambda e: e.step(K.LF_MID, x, x, p, y, eps, sig, 1.0, ws), world, rank, sharding, device)
+        dt, loss, in_situ = timed_steps(eng, x, p, y, eps, sig, ws, args.warmup, args.steps, world, rank, sharding, device)
         ms_per_step = 1e3 * dt / args.steps
         value = world * B * args.steps / dt
         # the one collective of the design: per-chain results gathered once, after the timed region (RCCL over xGMI at N > 1)

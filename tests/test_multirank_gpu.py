@@ -63,3 +63,16 @@ def test_bench_two_rank_control_flow_on_the_shared_gpu(tmp_path):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['global_chains'] == 8 and line['final_gather']['chains'] == 8
     assert line['value'] > 0 and line['scaling'] == 'weak' and 'REHEARSAL' in line['config']['workload']
+
+
+def test_bench_ranks_halve_the_score_chunk_together(tmp_path):
+    """An out-of-memory error on ONE rank (injected on rank 1) makes EVERY rank retry with half the score chunk, so the
+    barriers of the timed region still line up (bench.settle_score_chunk)."""
+    out = _torchrun(2, os.path.join(ROOT, 'bench.py'),
+                    ['--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '4', '--chunk', '4', '--tiny-score',
+                     '--rehearse-shared-gpu', '--no-cpu-baseline', '--roofline-launches', '8'], ROOT,
+                    extra_env={'NHMC_BENCH_FAKE_OOM': '1'})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'every rank retries with --chunk 2' in out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['config']['score_chunk'] == 2 and line['final_gather']['chains'] == 8 and line['value'] > 0
