@@ -174,8 +174,10 @@ int nhmc_sr_H(const float* x, float* y, int ratio, int n_chains, int channels, i
 int nhmc_sr_Ht(const float* y, float* x, int ratio, float scale, int n_chains, int channels,
                int dim, nhmc_stream_t stream);
 
-/* Colorization (Hfuncs.py:655-695): y = sum_c w_c x_c per pixel.  w: HOST array of `channels` (<= 4) weights
- * (passed by value to the kernel); for nhmc_color_Ht pass w_c for H^T and w_c / |w|^2 for H^+.
+/* Colorization (Hfuncs.py:655-695).  w: HOST array of channels + 2 floats (channels <= 4; passed by value to the
+ * kernel): the SVD (u, s, V) of the 1 x C grey row as the reference holds it -- V[0,0] .. V[C-1,0], s, U[0,0].
+ *   H x = u * (s * ((v_0 x_0 + v_1 x_1) + v_2 x_2)),  H^T y = v_c * (s * (u * y)),  H^+ y = v_c * ((u * y) / s),
+ * each product and sum rounded in this order (torch's CPU ops on the reference's composition: same bits).
  * loss partials: nhmc_color_tiles(hw) per chain. */
 int nhmc_color_tiles(int64_t hw);
 int nhmc_data_color(const float* xt, const float* y, const float* w, int apply_clip, float* g_xt,
@@ -187,8 +189,8 @@ int nhmc_ddim_mix_bwd_color(const float* xt, const float* e, int e_channels, con
                             int channels, int64_t hw, nhmc_stream_t stream);
 int nhmc_color_H(const float* x, const float* w, float* y, int n_chains, int channels, int64_t hw,
                  nhmc_stream_t stream);
-int nhmc_color_Ht(const float* y, const float* w, float* x, int n_chains, int channels, int64_t hw,
-                  nhmc_stream_t stream);
+int nhmc_color_Ht(const float* y, const float* w, int pinv, float* x, int n_chains, int channels, int64_t hw,
+                  nhmc_stream_t stream);                                    /* pinv: 0 = H^T, 1 = H^+ */
 
 /* Walsh-Hadamard compressive sensing (Hfuncs.py:611-651): y[k*C + c] = (FWHT(x_c) / d)[perm[k]], k < d*d/ratio;
  * H^T = H^+.  kslot: int32[d*d], position -> k or -1 (inverse of perm restricted to the kept rows).  m = row length

@@ -41,7 +41,7 @@ SIGNATURES = {
     'nhmc_data_color': (I, [P, P, P, I, P, P, I, I, I64, P]),
     'nhmc_ddim_mix_bwd_color': (I, [P, P, I, P, P, P, P, P, P, P, I, I, I64, P]),
     'nhmc_color_H': (I, [P, P, P, I, I, I64, P]),
-    'nhmc_color_Ht': (I, [P, P, P, I, I, I64, P]),
+    'nhmc_color_Ht': (I, [P, P, I, P, I, I, I64, P]),
     'nhmc_cs_tiles': (I, [I, I]),
     'nhmc_cs_H': (I, [P, P, P, P, I, I, I, I64, P]),
     'nhmc_cs_Ht': (I, [P, P, P, P, I, I, I, I64, P]),

@@ -1,16 +1,22 @@
 // Colorization operator (row f.3 of SURVEY.md section 8: remaining linear operators on the data-term interface).
-// Replaces obs_functions/Hfuncs.py:655-695: per pixel y = sum_c w_c x_c (w = U s V^T of the 1x3 matrix
-// [0.3333 0.3334 0.3333]), H^T y = w_c y, H^+ y = w_c y / |w|^2.  One thread owns a float4 of pixels and reads the
-// C channel planes at the same offset: coalesced 16-byte accesses, nothing to stage or shuffle.
-// HBM-bound: data term R xt (T) + R y (T/C) + W g (T).
+// Replaces obs_functions/Hfuncs.py:655-695.  With (u, s, V) the SVD of the 1 x C row [0.3333 0.3334 0.3333] and
+// v_c = V[c,0], per pixel
+//     H x   = u * (s * ((v_0 x_0 + v_1 x_1) + v_2 x_2))        (Vt: a [C x C] @ [C x 1] matmul per pixel, torch sums
+//                                                               its K = C products left to right, each rounded; :673-680,
+//                                                               then singulars *, then U)
+//     H^T y = v_c * (s * (u * y)),     H^+ y = v_c * ((u * y) / s)                     (:65-90 composed with :682-695)
+//     d loss / d x_c = v_c * (s * (u * (-(2 r))))               (autograd of the line above, in its order)
+// in exactly these roundings, so the operator, the data term and its gradient reproduce torch's CPU bits (G15 replay).
+// One thread owns a float4 of pixels and reads the C channel planes at the same offset: coalesced 16-byte accesses,
+// nothing to stage or shuffle.  HBM-bound: data term R xt (T) + R y (T/C) + W g (T).
 #include "nhmc_common.h"
 
 namespace {
 
 constexpr int MAXC = 4;
-struct W { float w[MAXC]; };
+struct W { float w[MAXC]; float s, u; };     // w[c] = V[c,0]; singular value; U[0,0] (= +-1)
 
-// MODE 0: data term, 1: H, 2: H^T / H^+ (weights already scaled by the host)
+// MODE 0: data term, 1: H, 2: H^T, 3: H^+
 template <int MODE>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__ xin, const float4* __restrict__ yin,
                                                       float4* __restrict__ out, W wt, int channels, int apply_clip,
@@ -21,11 +27,15 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__
   float acc = 0.0f;
   if (live) {
     const int64_t xbase = (int64_t)chain * channels * hw4, ybase = (int64_t)chain * hw4;
-    if (MODE == 2) {
+    if (MODE >= 2) {
       const float4 y = nhmc_ldnt(&yin[ybase + q]);
+      const float yv[4] = {y.x, y.y, y.z, y.w};
+      float t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = MODE == 2 ? wt.s * (wt.u * yv[k]) : (wt.u * yv[k]) / wt.s;
       for (int c = 0; c < channels; ++c) {
         float4 o;
-        o.x = wt.w[c] * y.x; o.y = wt.w[c] * y.y; o.z = wt.w[c] * y.z; o.w = wt.w[c] * y.w;
+        o.x = wt.w[c] * t[0]; o.y = wt.w[c] * t[1]; o.z = wt.w[c] * t[2]; o.w = wt.w[c] * t[3];
         nhmc_stnt(&out[xbase + (int64_t)c * hw4 + q], o);
       }
     } else {
@@ -37,9 +47,14 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__
           xv[c] = nhmc_ldnt(&xin[xbase + (int64_t)c * hw4 + q]);
           const float* e = reinterpret_cast<const float*>(&xv[c]);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) s[k] += wt.w[c] * ((MODE == 0 && apply_clip) ? nhmc_clip1(e[k]) : e[k]);
+          for (int k = 0; k < 4; ++k) {
+            const float term = wt.w[c] * ((MODE == 0 && apply_clip) ? nhmc_clip1(e[k]) : e[k]);
+            s[k] = c == 0 ? term : s[k] + term;
+          }
         }
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] = wt.u * (wt.s * s[k]);
       if (MODE == 1) {
         nhmc_stnt(&out[ybase + q], make_float4(s[0], s[1], s[2], s[3]));
       } else {
@@ -55,7 +70,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__
             float* oe = reinterpret_cast<float*>(&o);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              float gr = -(2.0f * r[k]) * wt.w[c];
+              float gr = wt.w[c] * (wt.s * (wt.u * (-(2.0f * r[k]))));
               if (apply_clip) gr = gr * nhmc_in1(e[k]);
               oe[k] = gr;
             }
@@ -99,10 +114,13 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_color(
         for (int k = 0; k < 4; ++k) {
           uu[c][k] = (xe[k] - ee[k] * c1) / c2;
           pre[c][k] = c3 * nhmc_clip1(uu[c][k]) + c4 * ee[k];
-          s[k] += wt.w[c] * nhmc_clip1(pre[c][k]);
+          const float term = wt.w[c] * nhmc_clip1(pre[c][k]);
+          s[k] = c == 0 ? term : s[k] + term;
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = wt.u * (wt.s * s[k]);
     const float4 y = nhmc_ldnt(&yin[(int64_t)chain * hw4 + q]);
     const float r[4] = {y.x - s[0], y.y - s[1], y.z - s[2], y.w - s[3]};
 #pragma unroll
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_color(
         float* gee = reinterpret_cast<float*>(&oe);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float gin = -(2.0f * r[k]) * wt.w[c];
+          float gin = wt.w[c] * (wt.s * (wt.u * (-(2.0f * r[k]))));
           gin = gin * nhmc_in1(pre[c][k]);
           const float gu = ((gin * c3) * nhmc_in1(uu[c][k])) / c2;
           gx[k] = gu;
@@ -136,11 +154,18 @@ bool bad(int n_chains, int channels, int64_t hw) {
   return n_chains <= 0 || n_chains > 65535 || channels <= 0 || channels > MAXC || hw <= 0 || (hw & 3);
 }
 
+W weights(const float* w_host, int channels) {          // [v_0 .. v_{C-1}, s, u]
+  W wt;
+  for (int c = 0; c < MAXC; ++c) wt.w[c] = c < channels ? w_host[c] : 0.0f;
+  wt.s = w_host[channels];
+  wt.u = w_host[channels + 1];
+  return wt;
+}
+
 template <int MODE>
 int launch(const float* xin, const float* yin, float* out, const float* w_host, int channels, int apply_clip,
            double* ws, int n_chains, int64_t hw, hipStream_t st) {
-  W wt;
-  for (int c = 0; c < MAXC; ++c) wt.w[c] = c < channels ? w_host[c] : 0.0f;
+  const W wt = weights(w_host, channels);
   const int64_t hw4 = hw / 4;
   dim3 grid((unsigned)((hw4 + NHMC_BLOCK - 1) / NHMC_BLOCK), (unsigned)n_chains);
   NHMC_LAUNCH((k_color<MODE>), grid, dim3(NHMC_BLOCK), 0, st, (const float4*)xin, (const float4*)yin, (float4*)out, wt,
@@ -152,7 +177,7 @@ int launch(const float* xin, const float* yin, float* out, const float* w_host, 
 
 extern "C" int nhmc_color_tiles(int64_t hw) { return (int)((hw / 4 + NHMC_BLOCK - 1) / NHMC_BLOCK); }
 
-// w: HOST array of `channels` weights (they travel as a kernel argument).
+// w: HOST array [V[0,0] .. V[C-1,0], s, U[0,0]] of the row's SVD (channels + 2 floats; they travel as a kernel argument).
 extern "C" int nhmc_data_color(const float* xt, const float* y, const float* w, int apply_clip, float* g_xt,
                                double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream) {
   if (!xt || !y || !w || !g_xt || !loss_ws) return NHMC_ERR_ARG;
@@ -169,11 +194,13 @@ extern "C" int nhmc_color_H(const float* x, const float* w, float* y, int n_chai
   return launch<1>(x, nullptr, y, w, channels, 0, nullptr, n_chains, hw, nhmc_s(stream));
 }
 
-extern "C" int nhmc_color_Ht(const float* y, const float* w, float* x, int n_chains, int channels, int64_t hw,
+// pinv = 0: H^T y;  1: H^+ y
+extern "C" int nhmc_color_Ht(const float* y, const float* w, int pinv, float* x, int n_chains, int channels, int64_t hw,
                              nhmc_stream_t stream) {
   if (!x || !w || !y) return NHMC_ERR_ARG;
-  if (bad(n_chains, channels, hw)) return NHMC_ERR_SHAPE;
+  if (bad(n_chains, channels, hw) || (pinv && w[channels] == 0.0f)) return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(x) || !nhmc_aligned16(y)) return NHMC_ERR_ALIGN;
+  if (pinv) return launch<3>(nullptr, y, x, w, channels, 0, nullptr, n_chains, hw, nhmc_s(stream));
   return launch<2>(nullptr, y, x, w, channels, 0, nullptr, n_chains, hw, nhmc_s(stream));
 }
 
@@ -184,8 +211,7 @@ extern "C" int nhmc_ddim_mix_bwd_color(const float* xt, const float* e, int e_ch
   if (bad(n_chains, channels, hw) || (e_channels != channels && e_channels != 2 * channels)) return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(y) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e))
     return NHMC_ERR_ALIGN;
-  W wt;
-  for (int c = 0; c < MAXC; ++c) wt.w[c] = c < channels ? w[c] : 0.0f;
+  const W wt = weights(w, channels);
   const int64_t hw4 = hw / 4;
   dim3 grid((unsigned)((hw4 + NHMC_BLOCK - 1) / NHMC_BLOCK), (unsigned)n_chains);
   NHMC_LAUNCH(k_mix_bwd_color, grid, dim3(NHMC_BLOCK), 0, nhmc_s(stream), (const float4*)xt, (const float4*)e,

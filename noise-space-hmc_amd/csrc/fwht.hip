@@ -13,13 +13,19 @@
 //                          scales by 1/d and applies the epilogue: plain store, scatter to y (H), residual against
 //                          y + loss partial (data term, writes the zero-filled spectrum for the adjoint), or
 //                          -2 * clip-mask (data-term gradient).
+// The data term's adjoint runs the stages in DESCENDING order -- columns first (h = d^2/2 .. d), then rows
+// (h = d/2 .. 1) -- because that is what autograd does with the reference's loop: the backward of stage h is the same
+// butterfly, visited last-to-first, after the backward of the final "/ img_dim" (a power of two: exact wherever it is
+// applied).  Mathematically the same transform, but sums of different pairs: with the ascending order the gradient sat
+// 1e-7 from the reference's and the G15 replay left the reference's run after 183 trajectories.
 // HBM-bound: each pass reads and writes the image once (2T); a data term is 4 passes.
 #include "nhmc_common.h"
 
 namespace {
 
 enum { PRO_NONE = 0, PRO_CLIP = 1, PRO_GATHER = 2 };
-enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4 };
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4, EPI_RAW = 5 };
+// EPI_RAW: plain store without the 1/d scale (the descending column pass; the row pass that follows scales)
 // EPI_VJP: the gradient goes straight through the VJP of the last DDIM step (k_mix_bwd with final_clip = 1); `xt` is then
 // the step's input and e / g_e are [chain][e_channels][d][d]
 struct VjpArgs { const float* e; float* g_e; const float* at; const float* at_next; int e_channels; };
@@ -46,10 +52,13 @@ template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2)
 template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
 // ---- pass A: rows -------------------------------------------------------------------------------------
-template <int V, int PRO>
+// DESC: stages h = d/2 .. 1 (the second half of the adjoint), then * 1/d and the gradient epilogue EPI (EPI_GRAD: -2 x
+// clip mask of xt; EPI_VJP: through the last DDIM step's VJP); ascending passes store plainly (EPI_STORE).
+template <int V, int PRO, bool DESC = false, int EPI = EPI_STORE>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_rows(const float* __restrict__ in, const float* __restrict__ y,
                                                           const int32_t* __restrict__ kslot, float* __restrict__ out,
-                                                          int d, int channels, int64_t m, int64_t total_rows) {
+                                                          int d, int channels, int64_t m, int64_t total_rows,
+                                                          const float* __restrict__ xt, int apply_clip, VjpArgs vj) {
   const int lpr = d / V;                               // lanes per row (<= 64)
   const int rows_per_wave = NHMC_WAVE / lpr;
   const int lane = threadIdx.x & 63;
@@ -80,39 +89,88 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_rows(const float* __restric
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = 0.0f;
   }
-  // in-register stages h = 1 .. V/2
+  if (!DESC) {
+    // in-register stages h = 1 .. V/2
 #pragma unroll
-  for (int h = 1; h < V; h <<= 1) {
+    for (int h = 1; h < V; h <<= 1) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      if ((e & h) == 0) {
-        const float a = v[e], b = v[e + h];
-        v[e] = a + b;
-        v[e + h] = a - b;
+      for (int e = 0; e < V; ++e) {
+        if ((e & h) == 0) {
+          const float a = v[e], b = v[e + h];
+          v[e] = a + b;
+          v[e + h] = a - b;
+        }
       }
     }
-  }
-  // cross-lane stages h = V .. d/2  <->  lane xor (h / V)
-  for (int s = 1; s < lpr; s <<= 1) {
-    const bool upper = (lane & s) != 0;
+    // cross-lane stages h = V .. d/2  <->  lane xor (h / V)
+    for (int s = 1; s < lpr; s <<= 1) {
+      const bool upper = (lane & s) != 0;
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const float other = __shfl_xor(v[e], s, NHMC_WAVE);
-      v[e] = upper ? other - v[e] : v[e] + other;
+      for (int e = 0; e < V; ++e) {
+        const float other = __shfl_xor(v[e], s, NHMC_WAVE);
+        v[e] = upper ? other - v[e] : v[e] + other;
+      }
+    }
+  } else {
+    for (int s = lpr >> 1; s >= 1; s >>= 1) {                       // h = d/2 .. V
+      const bool upper = (lane & s) != 0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float other = __shfl_xor(v[e], s, NHMC_WAVE);
+        v[e] = upper ? other - v[e] : v[e] + other;
+      }
+    }
+#pragma unroll
+    for (int h = V >> 1; h >= 1; h >>= 1) {                         // h = V/2 .. 1
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        if ((e & h) == 0) {
+          const float a = v[e], b = v[e + h];
+          v[e] = a + b;
+          v[e + h] = a - b;
+        }
+      }
     }
   }
   if (live) {
     const int64_t base = row * d + j0;
     typename Vec<V>::type w;
     float* we = reinterpret_cast<float*>(&w);
+    if (EPI == EPI_STORE) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) we[e] = v[e];
+      for (int e = 0; e < V; ++e) we[e] = v[e];
+    } else {
+      const float scale = 1.0f / (float)d;
+      const typename Vec<V>::type xw = *reinterpret_cast<const typename Vec<V>::type*>(&xt[base]);
+      const float* xe = reinterpret_cast<const float*>(&xw);
+      if (EPI == EPI_GRAD) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          float g = -(2.0f * (v[e] * scale));
+          if (apply_clip) g = g * nhmc_in1(xe[e]);
+          we[e] = g;
+        }
+      } else {                                                      // EPI_VJP
+        const int64_t plane = row / d;
+        const int c = (int)(plane % channels);
+        const int64_t chain = plane / channels;
+        const VjpCoef kc = vjp_coef(vj, chain);
+        const int64_t eoff = (chain * vj.e_channels + c) * (int64_t)d * d + (row % d) * d + j0;
+        const typename Vec<V>::type ew = *reinterpret_cast<const typename Vec<V>::type*>(&vj.e[eoff]);
+        const float* ee = reinterpret_cast<const float*>(&ew);
+        typename Vec<V>::type gw;
+        float* ge = reinterpret_cast<float*>(&gw);
+#pragma unroll
+        for (int e = 0; e < V; ++e) vjp_elem(kc, v[e] * scale, xe[e], ee[e], we[e], ge[e]);
+        *reinterpret_cast<typename Vec<V>::type*>(&vj.g_e[eoff]) = gw;
+      }
+    }
     *reinterpret_cast<typename Vec<V>::type*>(&out[base]) = w;
   }
 }
 
 // ---- pass B: columns ----------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool DESC = false>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restrict__ in, float* __restrict__ out,
                                                           const float* __restrict__ y, float* __restrict__ y_out,
                                                           const int32_t* __restrict__ kslot, const float* __restrict__ xt,
@@ -130,7 +188,8 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
     tile[idx] = src[(int64_t)i * d + c0 + cc];
   }
   __syncthreads();
-  for (int h = 1; h < d; h <<= 1) {
+  for (int st = 1; st < d; st <<= 1) {
+    const int h = DESC ? (d >> 1) / st : st;                        // ascending 1 .. d/2, or descending d/2 .. 1
     for (int idx = threadIdx.x; idx < n / 2; idx += NHMC_BLOCK) {
       const int cc = idx % pc, pr = idx / pc;                       // pair number -> lower row index
       const int i = (pr / h) * 2 * h + (pr % h);
@@ -147,7 +206,9 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
     const int64_t q = (int64_t)i * d + c0 + cc;                     // position inside the plane
     const int64_t off = plane * (int64_t)d * d + q;
     float v = tile[idx] * scale;
-    if (EPI == EPI_STORE) {
+    if (EPI == EPI_RAW) {
+      out[off] = tile[idx];
+    } else if (EPI == EPI_STORE) {
       out[off] = v;
     } else if (EPI == EPI_SCATTER) {
       const int k = kslot[q];
@@ -183,7 +244,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
 // group and 16 rows: first the 16 CONSECUTIVE rows rg*16 + m (stages h = 1,2,4,8 in registers), one exchange through
 // LDS, then the 16 STRIDED rows rg + 16 m (stages h = 16..128 in registers) -- ascending h as in the reference, one
 // LDS write + read of the panel instead of eight.
-template <int EPI>
+template <int EPI, bool DESC = false>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __restrict__ in, float* __restrict__ out,
                                                              const float* __restrict__ y, float* __restrict__ y_out,
                                                              const int32_t* __restrict__ kslot, const float* __restrict__ xt,
@@ -198,32 +259,66 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __rest
   const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
   const float* __restrict__ src = in + plane * (int64_t)D * D + c0 + cg * 4;
   nhmc_v4f v[16];
+  if (!DESC) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const nhmc_v4f*>(&src[(int64_t)(rg * 16 + k) * D]);
+    for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const nhmc_v4f*>(&src[(int64_t)(rg * 16 + k) * D]);
 #pragma unroll
-  for (int h = 1; h < 16; h <<= 1) {
+    for (int h = 1; h < 16; h <<= 1) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if ((k & h) == 0) {
-        const nhmc_v4f a = v[k], b = v[k + h];
-        v[k] = a + b;
-        v[k + h] = a - b;
+      for (int k = 0; k < 16; ++k) {
+        if ((k & h) == 0) {
+          const nhmc_v4f a = v[k], b = v[k + h];
+          v[k] = a + b;
+          v[k + h] = a - b;
+        }
       }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) tile[(rg * 16 + k) * (PC / 4) + cg] = v[k];
-  __syncthreads();
+    for (int k = 0; k < 16; ++k) tile[(rg * 16 + k) * (PC / 4) + cg] = v[k];
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = tile[(rg + 16 * k) * (PC / 4) + cg];
+    for (int k = 0; k < 16; ++k) v[k] = tile[(rg + 16 * k) * (PC / 4) + cg];
 #pragma unroll
-  for (int h = 1; h < 16; h <<= 1) {                                  // row stride 16*h
+    for (int h = 1; h < 16; h <<= 1) {                                // row stride 16*h
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if ((k & h) == 0) {
-        const nhmc_v4f a = v[k], b = v[k + h];
-        v[k] = a + b;
-        v[k + h] = a - b;
+      for (int k = 0; k < 16; ++k) {
+        if ((k & h) == 0) {
+          const nhmc_v4f a = v[k], b = v[k + h];
+          v[k] = a + b;
+          v[k + h] = a - b;
+        }
+      }
+    }
+  } else {
+    // descending: the STRIDED rows rg + 16 k first (row strides 128, 64, 32, 16), exchange, then the consecutive rows
+    // rg*16 + k (strides 8, 4, 2, 1); the result is left in the consecutive-row ownership
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const nhmc_v4f*>(&src[(int64_t)(rg + 16 * k) * D]);
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if ((k & h) == 0) {
+          const nhmc_v4f a = v[k], b = v[k + h];
+          v[k] = a + b;
+          v[k + h] = a - b;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile[(rg + 16 * k) * (PC / 4) + cg] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = tile[(rg * 16 + k) * (PC / 4) + cg];
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if ((k & h) == 0) {
+          const nhmc_v4f a = v[k], b = v[k + h];
+          v[k] = a + b;
+          v[k + h] = a - b;
+        }
       }
     }
   }
@@ -231,11 +326,13 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __rest
   float acc = 0.0f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const int i = rg + 16 * k;
+    const int i = DESC ? rg * 16 + k : rg + 16 * k;
     const int64_t q = (int64_t)i * D + c0 + cg * 4;
     const int64_t off = plane * (int64_t)D * D + q;
     nhmc_v4f val = v[k] * scale;
-    if (EPI == EPI_STORE) {
+    if (EPI == EPI_RAW) {
+      *reinterpret_cast<nhmc_v4f*>(&out[off]) = v[k];
+    } else if (EPI == EPI_STORE) {
       *reinterpret_cast<nhmc_v4f*>(&out[off]) = val;
     } else if (EPI == EPI_SCATTER) {
       const int4 ks = *reinterpret_cast<const int4*>(&kslot[q]);
@@ -296,31 +393,31 @@ int panel_cols(int dim) {                         // d = 256: the register fast 
   return pc > dim ? dim : (pc < 8 ? 8 : pc);
 }
 
-template <int PRO>
+template <int PRO, bool DESC = false, int EPI = EPI_STORE>
 int rows(const float* in, const float* y, const int32_t* kslot, float* out, int n_chains, int channels, int dim,
-         int64_t m, hipStream_t st) {
+         int64_t m, hipStream_t st, const float* xt = nullptr, int apply_clip = 0, VjpArgs vj = VjpArgs{}) {
   const int64_t total_rows = (int64_t)n_chains * channels * dim;
   const int V = dim >= 256 ? 4 : (dim >= 128 ? 2 : 1);
   const int rows_per_wave = NHMC_WAVE / (dim / V);
   const int64_t waves = (total_rows + rows_per_wave - 1) / rows_per_wave;
   dim3 grid((unsigned)((waves + 3) / 4)), block(NHMC_BLOCK);
   if (dim / V > 64) return NHMC_ERR_SHAPE;
-  if (V == 4) NHMC_LAUNCH((k_fwht_rows<4, PRO>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows);
-  else if (V == 2) NHMC_LAUNCH((k_fwht_rows<2, PRO>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows);
-  else NHMC_LAUNCH((k_fwht_rows<1, PRO>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows);
+  if (V == 4) NHMC_LAUNCH((k_fwht_rows<4, PRO, DESC, EPI>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows, xt, apply_clip, vj);
+  else if (V == 2) NHMC_LAUNCH((k_fwht_rows<2, PRO, DESC, EPI>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows, xt, apply_clip, vj);
+  else NHMC_LAUNCH((k_fwht_rows<1, PRO, DESC, EPI>), grid, block, 0, st, in, y, kslot, out, dim, channels, m, total_rows, xt, apply_clip, vj);
   return nhmc_launch_status();
 }
 
-template <int EPI>
+template <int EPI, bool DESC = false>
 int cols(const float* in, float* out, const float* y, float* y_out, const int32_t* kslot, const float* xt, double* ws,
          int n_chains, int channels, int dim, int64_t m, int apply_clip, hipStream_t st, VjpArgs vj = VjpArgs{}) {
   const int pc = panel_cols(dim);
   dim3 grid((unsigned)(dim / pc), (unsigned)(n_chains * channels)), block(NHMC_BLOCK);
   if (dim == 256) {
-    NHMC_LAUNCH((k_fwht_cols256<EPI>), grid, block, 0, st, in, out, y, y_out, kslot, xt, ws, channels, m, apply_clip, vj);
+    NHMC_LAUNCH((k_fwht_cols256<EPI, DESC>), grid, block, 0, st, in, out, y, y_out, kslot, xt, ws, channels, m, apply_clip, vj);
     return nhmc_launch_status();
   }
-  NHMC_LAUNCH((k_fwht_cols<EPI>), grid, block, (size_t)dim * pc * sizeof(float), st, in, out, y, y_out, kslot, xt, ws,
+  NHMC_LAUNCH((k_fwht_cols<EPI, DESC>), grid, block, (size_t)dim * pc * sizeof(float), st, in, out, y, y_out, kslot, xt, ws,
               dim, pc, channels, m, apply_clip, vj);
   return nhmc_launch_status();
 }
@@ -363,8 +460,9 @@ extern "C" int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslo
   if (apply_clip) { if ((rc = rows<PRO_CLIP>(xt, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc; }
   else            { if ((rc = rows<PRO_NONE>(xt, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc; }
   if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
-  if ((rc = rows<PRO_NONE>(B, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
-  return cols<EPI_GRAD>(A, g_xt, nullptr, nullptr, nullptr, xt, nullptr, n_chains, channels, dim, m, apply_clip, st);
+  // adjoint in autograd's order: column stages descending, then row stages descending with the gradient epilogue
+  if ((rc = cols<EPI_RAW, true>(B, A, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, m, 0, st))) return rc;
+  return rows<PRO_NONE, true, EPI_GRAD>(A, nullptr, nullptr, g_xt, n_chains, channels, dim, m, st, xt, apply_clip);
 }
 
 // nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last column
@@ -386,7 +484,7 @@ extern "C" int nhmc_data_cs_vjp(const float* xt_next, const float* y, const int3
   int rc;
   if ((rc = rows<PRO_NONE>(xt_next, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
   if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
-  if ((rc = rows<PRO_NONE>(B, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
+  if ((rc = cols<EPI_RAW, true>(B, A, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, m, 0, st))) return rc;
   const VjpArgs vj{e, g_e, at, at_next, e_channels};
-  return cols<EPI_VJP>(A, g_xt, nullptr, nullptr, nullptr, xt, nullptr, n_chains, channels, dim, m, 0, st, vj);
+  return rows<PRO_NONE, true, EPI_VJP>(A, nullptr, nullptr, g_xt, n_chains, channels, dim, m, st, xt, 0, vj);
 }

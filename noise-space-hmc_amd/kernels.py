@@ -283,12 +283,13 @@ def sr_Ht(y, ratio, channels, dim, scale):
 
 
 def _host_w(w):
+    """[V[0,0] .. V[C-1,0], s, U[0,0]]: the kernels read channels + 2 values."""
     arr = (C.c_float * len(w))(*[float(v) for v in w])
     return C.cast(arr, C.c_void_p), arr
 
 
 def data_color(xt, y, w, apply_clip=True, loss_out=None):
-    """w: sequence of per-channel weights (host) -> (loss [B] float64, g_xt)"""
+    """w: host sequence [V[0,0] .. V[C-1,0], s, U[0,0]] of the grey row's SVD -> (loss [B] float64, g_xt)"""
     lib = _lib.load()
     B, Cc, hw = xt.shape[0], xt.shape[1], xt[0, 0].numel()
     tiles = lib.nhmc_color_tiles(hw)
@@ -326,12 +327,14 @@ def color_H(x, w):
     return y
 
 
-def color_Ht(y, w, channels):
+def color_Ht(y, w, channels, pinv=False):
     lib = _lib.load()
     B, hw = y.shape
     x = torch.empty(B, channels * hw, dtype=torch.float32, device=y.device)
+    if len(w) != channels + 2:
+        raise _lib.NhmcError('colorization weights: channels + 2 values (V[:,0], s, U[0,0])')
     wp, keep = _host_w(w)
-    _lib.check(lib.nhmc_color_Ht(_p(y, torch.float32, 'y'), wp, _p(x), B, channels, hw, _stream()), 'nhmc_color_Ht')
+    _lib.check(lib.nhmc_color_Ht(_p(y, torch.float32, 'y'), wp, int(pinv), _p(x), B, channels, hw, _stream()), 'nhmc_color_Ht')
     return x
 
 

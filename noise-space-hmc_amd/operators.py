@@ -267,10 +267,9 @@ class Colorization(H_functions):
 
     def __init__(self, img_dim, device):
         self.channels, self.img_dim, self.device = 3, img_dim, device
-        U, s, Vh = torch.linalg.svd(torch.tensor([[0.3333, 0.3334, 0.3333]]))
+        U, s, V = torch.svd(torch.Tensor([[0.3333, 0.3334, 0.3333]]), some=False)     # the reference's call, :661
         self._s = float(s[0])
-        self.w = [float(U[0, 0] * s[0] * Vh[0, c]) for c in range(3)]           # H = U s V^T
-        self.w_pinv = [wc / self._s ** 2 for wc in self.w]
+        self.w = [float(V[c, 0]) for c in range(3)] + [float(s[0]), float(U[0, 0])]    # the kernels apply V^T, s, U in turn
         self.M = img_dim * img_dim
 
     def singulars(self):
@@ -283,7 +282,7 @@ class Colorization(H_functions):
         return K.color_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.w, self.channels)
 
     def H_pinv(self, vec):
-        return K.color_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.w_pinv, self.channels)
+        return K.color_Ht(vec.reshape(vec.shape[0], -1).contiguous(), self.w, self.channels, pinv=True)
 
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
         return K.data_color(xt, y, self.w, apply_clip, loss_out=loss_out)
@@ -347,16 +346,31 @@ class SRConv(H_functions):
     singular values is consistent (`repeat_interleave`, :599), so the operator is the plain separable one."""
 
     def __init__(self, kernel, channels, img_dim, device, stride=1):
+        Hs = strided_conv_matrix(kernel.detach().cpu().float(), img_dim, stride)
+        U, s, V = torch.svd(Hs, some=False)                         # the reference's call, :555
+        self._init_svd(U, s, V, channels, img_dim, stride, device)
+
+    @classmethod
+    def from_svd(cls, U, s, V, channels, img_dim, device, stride=1):
+        """Exported factors of a reference instance (U_small [sd, sd], singulars_small [sd] as stored, i.e. already
+        thresholded, V_small [d, d])."""
+        self = cls.__new__(cls)
+        self._init_svd(U, s, V, channels, img_dim, stride, device)
+        return self
+
+    def _init_svd(self, U, s, V, channels, img_dim, stride, device):
         self.channels, self.img_dim, self.ratio = channels, img_dim, stride
         self.small_dim = sd = img_dim // stride
         if img_dim % 32 or sd % 32:
             raise NhmcError('SRConv needs img_dim and img_dim/stride to be multiples of 32')
-        Hs = strided_conv_matrix(kernel.detach().cpu().float(), img_dim, stride)
-        U, s, Vh = torch.linalg.svd(Hs, full_matrices=False)
-        s = torch.where(s < 3e-2, torch.zeros_like(s), s)
+        # the reference applies V^T, the singular values and U one after the other; collapsing them into A is done in
+        # float64 so that A carries one fp32 rounding per entry instead of a 64-term fp32 accumulation (the loss
+        # amplifies an operator perturbation by |H x| / |r|)
+        U, s, Vh = U.detach().cpu().double(), s.detach().cpu().double(), V.detach().cpu().double().t()[:sd]
+        s = torch.where(s < 3e-2, torch.zeros_like(s), s)           # :557-558
         sinv = torch.where(s != 0, 1.0 / s, torch.zeros_like(s))
-        A = (U * s) @ Vh                                            # [sd, d]
-        Ap = (Vh.t() * sinv) @ U.t()                                # [d, sd]  pseudo-inverse
+        A = ((U * s) @ Vh).float()                                  # [sd, d]
+        Ap = ((Vh.t() * sinv) @ U.t()).float()                      # [d, sd]  pseudo-inverse
         self.A, self.At = A.contiguous().to(device), A.t().contiguous().to(device)
         self.ApT, self.Ap = Ap.t().contiguous().to(device), Ap.contiguous().to(device)
         self.M = channels * sd * sd

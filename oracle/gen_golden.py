@@ -161,12 +161,17 @@ def g3_ddim(ms, dim=32):
     save(f'g3_ddim_{dim}.npz', x=np32(x), w=np32(w), xt=np32(xt), grad=np32(grad))
 
 
-def g4_hmc(ms, deg, dim=32, seed=5678, f64=False):
+def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=None):
     """f64=True -> g14_hmc_f64_*: the same reference run with the tiny score evaluated in float64 (oracle.tiny_score.F64Score,
-    the model is hmc()'s argument); stores every uniform and -dH so a GPU test can replay the whole run on the same tape."""
+    the model is hmc()'s argument); stores every uniform and -dH so a GPU test can replay the whole run on the same tape.
+    op / out_name / extra: another reference operator object, the fixture's file name and its operator data
+    (oracle/gen_golden_hmc_ops2.py -> g15_*)."""
     from algos.unconditional import Unconditional
-    ops, missing = build_ops(ms, dim, seed=900 + dim)
-    Hf = ops[deg]
+    if op is None:
+        ops, missing = build_ops(ms, dim, seed=900 + dim)
+        Hf = ops[deg]
+    else:
+        Hf, missing = op, torch.zeros(0, dtype=torch.long)
     net = tiny_model()
     if f64:
         from oracle.tiny_score import F64Score
@@ -234,7 +239,8 @@ def g4_hmc(ms, deg, dim=32, seed=5678, f64=False):
         for k in ('pos_first', 'pos_last', 'dec_last', 'dec_init'):
             arrays.pop(k)
         arrays['p_last'] = np32(rec['p_last'][0])
-    save(f'g14_hmc_f64_{deg}_{dim}.npz' if f64 else f'g4_hmc_{deg}_{dim}.npz', **arrays)
+    arrays.update(extra or {})
+    save(out_name or (f'g14_hmc_f64_{deg}_{dim}.npz' if f64 else f'g4_hmc_{deg}_{dim}.npz'), **arrays)
     print(f'   {deg}: {len(rec["u"])} iterations, {len(psnr)} accepts, final PSNR {psnr[-1]:.3f}')
 
 

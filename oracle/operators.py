@@ -164,26 +164,33 @@ class SpectralBlurRef:
 
 
 class ColorRef:
-    """Hfuncs.py:655-695 (Colorization): y = U00 * s * sum_c V[c,0] x_c per pixel with the SVD of
-    [[0.3333, 0.3334, 0.3333]]; H^T spreads w_c y, H^+ spreads w_c y / s^2."""
+    """Hfuncs.py:655-695 (Colorization) in the reference's rounding order.  With (u, s, V) = svd([[0.3333, 0.3334,
+    0.3333]]) (:660-661) and v = V[:, 0]:  Vt (:673-680) is a [3 x 3] @ [3 x 1] matmul per pixel, whose K = 3 products
+    torch's CPU kernel rounds one by one and sums left to right; H (:65-71) then multiplies by the singular value and
+    by U[0,0]:  H x = u * (s * ((v0 x0 + v1 x1) + v2 x2)).  H^T y = v_c * (s * (u * y)) (:73-78 with the zero padding
+    of :691-695 contributing exact zeros), H^+ y = v_c * ((u * y) / s) (:80-90).  Reproduces the reference's whole
+    `hmc()` run bit for bit (G15 color)."""
 
     def __init__(self, img_dim):
         self.channels, self.img_dim, self.M = 3, img_dim, img_dim * img_dim
         U, s, V = torch.svd(torch.Tensor([[0.3333, 0.3334, 0.3333]]), some=False)
-        self.s = s[0]
-        self.w = (U[0, 0] * s[0]) * V[:, 0]
+        self.s, self.u, self.v = s[0], U[0, 0], V[:, 0].clone()
+        self.w = (U[0, 0] * s[0]) * V[:, 0]                       # the collapsed weights, for reference only
 
     def H(self, x):
-        B = x.shape[0]
-        return (x.reshape(B, 3, -1) * self.w.view(1, 3, 1)).sum(1)
+        X = x.reshape(x.shape[0], 3, -1)
+        spec = (self.v[0] * X[:, 0] + self.v[1] * X[:, 1]) + self.v[2] * X[:, 2]
+        return self.u * (self.s * spec)
 
     def Ht(self, y):
         B = y.shape[0]
-        return (y.reshape(B, 1, -1) * self.w.view(1, 3, 1)).reshape(B, -1)
+        t = self.s * (self.u * y.reshape(B, 1, -1))
+        return (self.v.view(1, 3, 1) * t).reshape(B, -1)
 
     def H_pinv(self, y):
         B = y.shape[0]
-        return (y.reshape(B, 1, -1) * (self.w / self.s ** 2).view(1, 3, 1)).reshape(B, -1)
+        t = (self.u * y.reshape(B, 1, -1)) / self.s
+        return (self.v.view(1, 3, 1) * t).reshape(B, -1)
 
 
 class WalshHadamardRef:

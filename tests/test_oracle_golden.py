@@ -171,3 +171,33 @@ def test_g14_oracle_reproduces_the_reference_run_with_the_f64_score(golden, tiny
     assert len(trace['accept']) == len(g['u']) and sum(trace['accept']) == 100
     assert np.allclose(-np.array(trace['dH']), g['neg_dH'], rtol=0, atol=0.05)
     assert rel(out.numpy(), g['out']) <= 2e-5
+
+
+def _g15_oracle_op(g, deg, dim):
+    if deg == 'color':
+        return operators.ColorRef(dim)
+    if deg == 'gauss':
+        return operators.SpectralBlurRef(T(g['gauss_U']), T(g['gauss_U']), T(g['gauss_V']), T(g['gauss_V']), T(g['gauss_D']))
+    if deg == 'cs4':
+        return operators.WalshHadamardRef(3, dim, int(g['ratio']), T(g['perm']))
+    if deg == 'box':
+        return operators.InpaintRef(3, dim, T(g['box_missing']))
+    if deg == 'sr16':
+        return operators.BlockMeanRef(3, dim, 16)
+    return operators.SeparableStridedRef(T(g['kernel']), 3, dim, int(g['factor']))
+
+
+@pytest.mark.parametrize('deg,dim', [('color', 32), ('cs4', 32), ('sr16', 32)])
+def test_g15_oracle_reproduces_the_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim):
+    """G15 = the reference's whole `hmc()` run per remaining operator (oracle/gen_golden_hmc_ops2.py).  Three of the six
+    on the CPU (the suite's time budget); all six are replayed on the GPU (tests/test_reference_run_gpu.py)."""
+    from oracle.tiny_score import F64Score
+    g = golden(f'g15_hmc_f64_{deg}_{dim}.npz')
+    torch.manual_seed(int(g['seed']))
+    trace = {}
+    out = hmc_ref.hmc_reference(T(g['x']), schedule.betas_fp32(), SEQ, SEQ_NEXT, F64Score(tiny_score), _g15_oracle_op(g, deg, dim),
+                                T(g['y_0']), T(g['x_orig']), tau=float(g['tau']), epsilon=float(g['epsilon']),
+                                m=float(g['m']), sigma_0=float(g['sigma_0']), trace=trace)
+    assert len(trace['accept']) == len(g['u']) and sum(trace['accept']) == 100
+    assert np.allclose(-np.array(trace['dH']), g['neg_dH'], rtol=0, atol=0.05)
+    assert rel(out.numpy(), g['out']) <= 2e-5

@@ -83,3 +83,71 @@ def test_whole_reference_run_on_the_gpu(golden, tiny_score, deg):
     opt2 = types.SimpleNamespace(**vars(opt), noise_source=sampler.TapeNoise(lambda it: P[it], lambda it: torch.tensor([u_play[it]])))
     out = sampler.hmc(T(g['x']).to(dev), 1, b, SEQ, SEQ_NEXT, algo, opt2, T(g['y_0']).to(dev), op, T(g['x_orig']).to(dev))
     assert out.shape == (20, 3, 32, 32) and torch.equal(out, res.samples[0])
+
+
+# ---- G15: the remaining operators ------------------------------------------------------------------
+# The reference's loss is not smooth: the final clip masks the gradient, so an implementation follows the reference's
+# run only as long as no decode lands within its own rounding distance of +-1.  Whole-run agreement therefore needs the
+# reference's arithmetic, not just its mathematics: the colorization kernels apply V^T, s, U in torch's rounding order,
+# the Walsh-Hadamard adjoint runs its butterfly stages in autograd's (descending) order, box inpainting and the block
+# mean reproduce torch's bits -- with the collapsed colour weights the replay left the reference's run after 62
+# trajectories, with an ascending adjoint after 183.  Measured on the MI355X: box, color, cs4 return bit-identical
+# images, sr16 4.7e-6, deblur_gauss (MFMA chain) 6.4e-6.  The bicubic operator is applied as A X A^T (two products)
+# where the reference applies V^T, the singular values and U in turn (four): every accept decision and energy difference
+# of the run is reproduced, the 20 images agree to 1.3e-4 .. 4.3e-4 (accumulated over 209 trajectories; the CPU
+# restatement of the same form: 3.6e-5), hence its own tolerance.
+IMAGE_TOL = {'bicubic2': 2e-3}
+
+
+def _g15_operator(g, deg, dim, dev):
+    import nhmc.operators as ops
+    if deg == 'color':
+        return ops.Colorization(dim, dev)
+    if deg == 'gauss':
+        return ops.Deblurring2D.from_factors(T(g['gauss_U']), T(g['gauss_U']), T(g['gauss_V']), T(g['gauss_V']), T(g['gauss_D']), dev)
+    if deg == 'cs4':
+        return ops.WalshHadamardCS(3, dim, int(g['ratio']), T(g['perm']), dev)
+    if deg == 'box':
+        return ops.Inpainting(3, dim, T(g['box_missing']), dev)
+    if deg == 'sr16':
+        return ops.SuperResolution(3, dim, 16, dev)
+    # the reference instance's own SVD factors (the host's LAPACK may return others: a 1e-6 operator difference that the
+    # loss amplifies by |H x| / |r|)
+    return ops.SRConv.from_svd(T(g['srconv_U']), T(g['srconv_s']), T(g['srconv_V']), 3, dim, dev, stride=int(g['factor']))
+
+
+@pytest.mark.parametrize('deg,dim', [('box', 32), ('sr16', 32), ('color', 32), ('gauss', 32), ('cs4', 32), ('bicubic2', 64)])
+def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim):
+    from nhmc import plugin, sampler
+    g = golden(f'g15_hmc_f64_{deg}_{dim}.npz')
+    dev = torch.device('cuda')
+    op = _g15_operator(g, deg, dim, dev)
+    n = len(g['u'])
+    torch.manual_seed(int(g['seed']))
+    P, U = [], []
+    for _ in range(n):
+        P.append(torch.randn(1, 3, dim, dim))
+        U.append(float(torch.rand(1)))
+    assert np.array_equal(np.array(U), g['u']) and np.array_equal(P[0].numpy(), g['p0']) and np.array_equal(P[-1].numpy(), g['p_last'])
+    prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
+    ref_acc = g['u'] < prob
+    assert int(ref_acc.sum()) == 100
+    ambiguous = np.abs(g['u'] - prob) < BAND
+    u_play = np.where(ambiguous, np.where(ref_acc, 0.0, 1.0), g['u']).astype(np.float32)
+    algo = plugin.HMC(F64Score(tiny_score).to(dev), op, float(g['sigma_0']))
+    opt = types.SimpleNamespace(tau=float(g['tau']), epsilon=float(g['epsilon']), m=float(g['m']), sigma_0=float(g['sigma_0']), quiet=True)
+    noise = sampler.TapeNoise(lambda it: P[min(it, n - 1)], lambda it: torch.tensor([u_play[min(it, n - 1)]]))
+    res = sampler.hmc_chains(T(g['x']).to(dev), osched.betas_fp32().to(dev), SEQ, SEQ_NEXT, algo, opt, T(g['y_0']).to(dev), op,
+                             T(g['x_orig']).to(dev), noise=noise, collect_trace=True, max_iters=n)
+    m = min(n, len(res.trace))
+    got_acc = np.array([bool(r['accept'][0]) for r in res.trace[:m]])
+    got_dH = np.array([float(r['dH'][0]) for r in res.trace[:m]])
+    small = np.abs(g['neg_dH'][:m]) < 50
+    off = (got_acc != ref_acc[:m]) | (small & (np.abs(got_dH + g['neg_dH'][:m]) > 0.05))
+    common = int(np.argmax(off)) if off.any() else m
+    worst = float(np.max(np.abs(got_dH[:common] + g['neg_dH'][:common])[small[:common]])) if common else float('nan')
+    whole = common == n and res.iters == n
+    err = rel(res.samples[0], T(g['out'])) if whole else float('nan')
+    print(f'{deg}: {n} trajectories in the reference run, common prefix {common}, max |dH - dH_ref| on it {worst:.4f}, '
+          f'returned images rel err {err:.2e}')
+    assert whole and err < IMAGE_TOL.get(deg, 1e-4)
