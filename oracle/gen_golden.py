@@ -161,11 +161,13 @@ def g3_ddim(ms, dim=32):
     save(f'g3_ddim_{dim}.npz', x=np32(x), w=np32(w), xt=np32(xt), grad=np32(grad))
 
 
-def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=None):
+def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=None, probe=0):
     """f64=True -> g14_hmc_f64_*: the same reference run with the tiny score evaluated in float64 (oracle.tiny_score.F64Score,
     the model is hmc()'s argument); stores every uniform and -dH so a GPU test can replay the whole run on the same tape.
     op / out_name / extra: another reference operator object, the fixture's file name and its operator data
-    (oracle/gen_golden_hmc_ops2.py -> g15_*)."""
+    (oracle/gen_golden_hmc_ops2.py -> g15_*).  probe > 0 (full-size runs, oracle/gen_golden_hmc_256.py -> g16_*): the seeded
+    inputs are NOT stored (the test regenerates x_orig, the observation noise and x from torch.Generator(11) in this
+    function's order, and the mask from its seed) and the returned images are stored as `probe` positions + norms."""
     from algos.unconditional import Unconditional
     if op is None:
         ops, missing = build_ops(ms, dim, seed=900 + dim)
@@ -239,6 +241,15 @@ def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=
         for k in ('pos_first', 'pos_last', 'dec_last', 'dec_init'):
             arrays.pop(k)
         arrays['p_last'] = np32(rec['p_last'][0])
+    if probe:
+        flat = out.reshape(out.shape[0], -1)
+        pos = torch.randperm(flat.shape[1], generator=torch.Generator().manual_seed(16))[:probe]
+        for k in ('x', 'x_orig', 'missing', 'out', 'p0', 'p_last'):
+            arrays.pop(k, None)
+        arrays.update(out_probe_pos=np32(pos).astype(np.int32), out_probe=np32(flat[:, pos]), out_norm=np32(flat.double().norm(dim=1)),
+                      out_absmax=np32(flat.abs().max()), missing_sum=np.array(int(missing.sum())), mask_seed=np.array(900 + dim),
+                      p0_head=np32(rec['p'][0].reshape(-1)[:64]), p_last_head=np32(rec['p_last'][0].reshape(-1)[:64]),
+                      x_head=np32(x.reshape(-1)[:64]), x_orig_head=np32(x_orig.reshape(-1)[:64]))
     arrays.update(extra or {})
     save(out_name or (f'g14_hmc_f64_{deg}_{dim}.npz' if f64 else f'g4_hmc_{deg}_{dim}.npz'), **arrays)
     print(f'   {deg}: {len(rec["u"])} iterations, {len(psnr)} accepts, final PSNR {psnr[-1]:.3f}')

@@ -151,3 +151,61 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
     print(f'{deg}: {n} trajectories in the reference run, common prefix {common}, max |dH - dH_ref| on it {worst:.4f}, '
           f'returned images rel err {err:.2e}')
     assert whole and err < IMAGE_TOL.get(deg, 1e-4)
+
+
+def test_whole_reference_run_at_baseline_image_size(golden, tiny_score):
+    """G16 (oracle/gen_golden_hmc_256.py): BASELINE configs[0] geometry -- 256 x 256, inpaint_random with 92 % of the
+    pixels missing, sigma_0 = 0.05, timesteps 3, tau 1.0, epsilon 0.05, one chain -- the reference's whole `hmc()` run
+    with the float64 tiny score, replayed through the kernels at the size the benchmark runs them.  The seeded inputs
+    are regenerated here in the generator's order; the 20 returned images are compared at 4096 probe positions and by
+    their norms."""
+    import nhmc.operators as ops
+    from nhmc import plugin, sampler
+    g = golden('g16_hmc_f64_inpaint_256.npz')
+    dim, dev = 256, torch.device('cuda')
+    gm = torch.Generator().manual_seed(int(g['mask_seed']))
+    r = 3 * torch.randperm(dim * dim, generator=gm)[: int(dim * dim * 0.92)].long()
+    missing = torch.cat([r, r + 1, r + 2], dim=0)
+    assert int(missing.sum()) == int(g['missing_sum'])
+    y_0 = T(g['y_0'])
+    gi = torch.Generator().manual_seed(11)
+    x_orig = torch.rand(1, 3, dim, dim, generator=gi) * 2 - 1
+    torch.randn(y_0.shape, generator=gi)                               # the observation noise (already inside y_0)
+    x = torch.randn(1, 3, dim, dim, generator=gi)
+    assert np.array_equal(x.reshape(-1)[:64].numpy(), g['x_head']) and np.array_equal(x_orig.reshape(-1)[:64].numpy(), g['x_orig_head'])
+    n = len(g['u'])
+    torch.manual_seed(int(g['seed']))
+    P, U = [], []
+    for _ in range(n):
+        P.append(torch.randn(1, 3, dim, dim))
+        U.append(float(torch.rand(1)))
+    assert np.array_equal(np.array(U), g['u'])
+    assert np.array_equal(P[0].reshape(-1)[:64].numpy(), g['p0_head']) and np.array_equal(P[-1].reshape(-1)[:64].numpy(), g['p_last_head'])
+    op = ops.Inpainting(3, dim, missing, dev)
+    prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
+    ref_acc = g['u'] < prob
+    assert int(ref_acc.sum()) == 100
+    ambiguous = np.abs(g['u'] - prob) < BAND
+    u_play = np.where(ambiguous, np.where(ref_acc, 0.0, 1.0), g['u']).astype(np.float32)
+    algo = plugin.HMC(F64Score(tiny_score).to(dev), op, float(g['sigma_0']))
+    opt = types.SimpleNamespace(tau=float(g['tau']), epsilon=float(g['epsilon']), m=float(g['m']), sigma_0=float(g['sigma_0']), quiet=True)
+    noise = sampler.TapeNoise(lambda it: P[min(it, n - 1)], lambda it: torch.tensor([u_play[min(it, n - 1)]]))
+    res = sampler.hmc_chains(x.to(dev), osched.betas_fp32().to(dev), SEQ, SEQ_NEXT, algo, opt, y_0.to(dev), op, x_orig.to(dev),
+                             noise=noise, collect_trace=True, max_iters=n)
+    m = min(n, len(res.trace))
+    got_acc = np.array([bool(t['accept'][0]) for t in res.trace[:m]])
+    got_dH = np.array([float(t['dH'][0]) for t in res.trace[:m]])
+    small = np.abs(g['neg_dH'][:m]) < 50
+    # H is ~1e5 here (196 608 elements): one fp32 ulp of it is 0.0078, so the energies agree to a few ulps at best
+    off = (got_acc != ref_acc[:m]) | (small & (np.abs(got_dH + g['neg_dH'][:m]) > 0.5))
+    common = int(np.argmax(off)) if off.any() else m
+    worst = float(np.max(np.abs(got_dH[:common] + g['neg_dH'][:common])[small[:common]])) if common else float('nan')
+    print(f'256 x 256 inpaint_random: {n} trajectories in the reference run, {int(ambiguous.sum())} inside the accept band, '
+          f'common prefix {common}, max |dH - dH_ref| on it {worst:.4f}')
+    assert common == n and res.iters == n
+    flat = res.samples[0].reshape(20, -1).cpu()
+    pos = T(g['out_probe_pos']).long()
+    err = float((flat[:, pos] - T(g['out_probe'])).abs().max() / float(g['out_absmax']))
+    nerr = float((flat.double().norm(dim=1) - T(g['out_norm'])).abs().max() / T(g['out_norm']).max())
+    print(f'returned images: probes rel err {err:.2e}, norms rel err {nerr:.2e}')
+    assert err < 1e-4 and nerr < 1e-5
