@@ -244,8 +244,8 @@ def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=
     if probe:
         flat = out.reshape(out.shape[0], -1)
         pos = torch.randperm(flat.shape[1], generator=torch.Generator().manual_seed(16))[:probe]
-        for k in ('x', 'x_orig', 'missing', 'out', 'p0', 'p_last'):
-            arrays.pop(k, None)
+        for k in ['x', 'x_orig', 'missing', 'out', 'p0', 'p_last'] + [k for k in arrays if k.startswith('aniso_')]:
+            arrays.pop(k, None)                                    # the aniso instance is G13's (checked by the caller)
         arrays.update(out_probe_pos=np32(pos).astype(np.int32), out_probe=np32(flat[:, pos]), out_norm=np32(flat.double().norm(dim=1)),
                       out_absmax=np32(flat.abs().max()), missing_sum=np.array(int(missing.sum())), mask_seed=np.array(900 + dim),
                       p0_head=np32(rec['p'][0].reshape(-1)[:64]), p_last_head=np32(rec['p_last'][0].reshape(-1)[:64]),

@@ -153,20 +153,30 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
     assert whole and err < IMAGE_TOL.get(deg, 1e-4)
 
 
-def test_whole_reference_run_at_baseline_image_size(golden, tiny_score):
+@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso'])
+def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     """G16 (oracle/gen_golden_hmc_256.py): BASELINE configs[0] geometry -- 256 x 256, inpaint_random with 92 % of the
     pixels missing, sigma_0 = 0.05, timesteps 3, tau 1.0, epsilon 0.05, one chain -- the reference's whole `hmc()` run
-    with the float64 tiny score, replayed through the kernels at the size the benchmark runs them.  The seeded inputs
-    are regenerated here in the generator's order; the 20 returned images are compared at 4096 probe positions and by
-    their norms."""
+    with the float64 tiny score, replayed through the kernels at the size the benchmark runs them; the same with
+    configs[2] / [3]'s operators (sr4; deblur_aniso = the reference instance G13 exported, on the MFMA pair kernels).
+    The seeded inputs are regenerated here in the generator's order; the 20 returned images are compared at 4096 probe
+    positions and by their norms."""
     import nhmc.operators as ops
     from nhmc import plugin, sampler
-    g = golden('g16_hmc_f64_inpaint_256.npz')
+    g = golden(f'g16_hmc_f64_{deg}_256.npz')
     dim, dev = 256, torch.device('cuda')
-    gm = torch.Generator().manual_seed(int(g['mask_seed']))
-    r = 3 * torch.randperm(dim * dim, generator=gm)[: int(dim * dim * 0.92)].long()
-    missing = torch.cat([r, r + 1, r + 2], dim=0)
-    assert int(missing.sum()) == int(g['missing_sum'])
+    if deg == 'inpaint':
+        gm = torch.Generator().manual_seed(int(g['mask_seed']))
+        r = 3 * torch.randperm(dim * dim, generator=gm)[: int(dim * dim * 0.92)].long()
+        missing = torch.cat([r, r + 1, r + 2], dim=0)
+        assert int(missing.sum()) == int(g['missing_sum'])
+        op = ops.Inpainting(3, dim, missing, dev)
+    elif deg == 'sr4':
+        op = ops.SuperResolution(3, dim, 4, dev)
+    else:
+        a = golden('g13_aniso_256.npz')
+        D = oops.SpectralBlurRef.multiplier_map(T(a['s_sorted']), T(a['perm'].astype(np.int64)), 3, dim)
+        op = ops.Deblurring2D.from_factors(T(a['U1']), T(a['U2']), T(a['V1']), T(a['V2']), D, dev)
     y_0 = T(g['y_0'])
     gi = torch.Generator().manual_seed(11)
     x_orig = torch.rand(1, 3, dim, dim, generator=gi) * 2 - 1
@@ -181,7 +191,6 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score):
         U.append(float(torch.rand(1)))
     assert np.array_equal(np.array(U), g['u'])
     assert np.array_equal(P[0].reshape(-1)[:64].numpy(), g['p0_head']) and np.array_equal(P[-1].reshape(-1)[:64].numpy(), g['p_last_head'])
-    op = ops.Inpainting(3, dim, missing, dev)
     prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
     ref_acc = g['u'] < prob
     assert int(ref_acc.sum()) == 100
@@ -200,7 +209,7 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score):
     off = (got_acc != ref_acc[:m]) | (small & (np.abs(got_dH + g['neg_dH'][:m]) > 0.5))
     common = int(np.argmax(off)) if off.any() else m
     worst = float(np.max(np.abs(got_dH[:common] + g['neg_dH'][:common])[small[:common]])) if common else float('nan')
-    print(f'256 x 256 inpaint_random: {n} trajectories in the reference run, {int(ambiguous.sum())} inside the accept band, '
+    print(f'256 x 256 {deg}: {n} trajectories in the reference run, {int(ambiguous.sum())} inside the accept band, '
           f'common prefix {common}, max |dH - dH_ref| on it {worst:.4f}')
     assert common == n and res.iters == n
     flat = res.samples[0].reshape(20, -1).cpu()
