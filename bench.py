@@ -26,7 +26,8 @@ Extra objects on the same line:
   hot_path_only the HIP side of one step THROUGH THE ENGINE (the score replaced by a resident tensor whose
                 backward hands back a resident gradient): what the sampler launches, minus the U-Net.
   by_deg        configs[2] / configs[3] operators (sr4, deblur_aniso): hot path, dominant data-term kernel
-                against its roofline (fp32 MFMA for the spectral chain), end-to-end chain-steps/s of a few steps.
+                against its roofline (fp32 MFMA for the spectral chain), end-to-end chain-steps/s of a few steps;
+                configs[4] (hmc_latent, 16 chains): a few end-to-end steps (`--latent` prints its full line).
   cpu_baseline  the oracle (CPU restatement, validated bit-exact against the reference) on the host cores:
                 with the U-Net in the loop (B = 1) and score-stubbed at B = 1 and B = 64.
 
@@ -450,6 +451,42 @@ def degradation_leg(device, deg, model, B, chunk, steps=2):
     return out
 
 
+def latent_problem(device, B, lo, chunk, seed=5678):
+    """BASELINE configs[4] on one rank: LDM U-Net + VQ-f4 first stage (random init), inpaint_random at 256 x 256 on the
+    decoded image, B chains of [C,64,64] latents with global chain ids lo .. lo+B-1."""
+    import nhmc.kernels as K
+    from nhmc import ldm, operators, plugin, sampler
+    torch.manual_seed(seed)
+    model = ldm.create_latent_model(ckpt=None, quiet=True).to(device)
+    op = operators.build_operator('inpaint_random', CH, DIM, device, generator=torch.Generator().manual_seed(seed))
+    algo = plugin.HMCLatent(model, op, 2 * SIGMA0_CLI)
+    table = torch.cat([model.alphas_cumprod_prev[0:1], model.alphas_cumprod])
+    seq, seq_next = [250, 500, 750], [-1, 250, 500]
+    eng = sampler.LeapfrogEngine(algo.score, op, None, seq, seq_next, device, chunk=chunk, alpha_table=table,
+                                 image_map=model.differentiable_decode_first_stage)
+    zshape = (B, model.channels, ZDIM, ZDIM)
+    x = K.randn_philox(zshape, seed, lo, 0, device=device)
+    p = K.randn_philox(zshape, seed, lo, 1, device=device)
+    x_true = K.randn_philox((B, CH, DIM, DIM), seed, lo, 2, device=device).clamp_(-1, 1)
+    y = op.H(x_true) + (2 * SIGMA0_CLI) * torch.randn(B, op.M, device=device,
+                                                       generator=torch.Generator(device=device).manual_seed(seed + lo))
+    eps = torch.full((B,), 0.1, dtype=torch.float64, device=device)            # main_sampling_latent.py:828-830 default
+    sig = torch.full((B,), 0.5, dtype=torch.float64, device=device)            # --sigma_y default, :832
+    ws = K.leapfrog_ws(B, x[0].numel(), device)
+    return dict(model=model, op=op, algo=algo, table=table, seq=seq, seq_next=seq_next, eng=eng, zshape=zshape, x=x, p=p, y=y,
+                eps=eps, sig=sig, ws=ws)
+
+
+def latent_leg(device, steps=2):
+    """configs[4] inside the default run: a few hmc_latent steps at 16 chains (`bench.py --latent` is the full line)."""
+    from nhmc import sharding
+    lp = latent_problem(device, B_LATENT, 0, None)
+    dt, _, _ = timed_steps(lp['eng'], lp['x'], lp['p'], lp['y'], lp['eps'], lp['sig'], lp['ws'], 1, steps, 1, 0, sharding, device)
+    return dict(value=round(B_LATENT * steps / dt, 3), unit='chain-steps/s', steps=steps, ms_per_step=round(1e3 * dt / steps, 2),
+                chains=B_LATENT, workload='BASELINE configs[4]: hmc_latent, [%d,64,64] latents, LDM U-Net + VQ-f4 decode in the loop, '
+                                          'inpaint_random at 256x256, eps=0.1 sigma_y=0.5, random-init fp32' % lp['model'].channels)
+
+
 def latent_main(args):
     """BASELINE configs[4]: one leapfrog step of hmc_latent = 3 x [LDM U-Net forward (no gradient: ddpm.py:892) + DDIM
     mix] + final clip + VQ codebook lookup + VQ-f4 decoder forward + inpainting data term at 256x256 + decoder backward
@@ -463,25 +500,9 @@ def latent_main(args):
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     B = args.batch or B_LATENT
-    seed = 5678
-    torch.manual_seed(seed)
-    model = ldm.create_latent_model(ckpt=None, quiet=True).to(device)
-    op = operators.build_operator('inpaint_random', CH, DIM, device, generator=torch.Generator().manual_seed(seed))
-    algo = plugin.HMCLatent(model, op, 2 * SIGMA0_CLI)
-    table = torch.cat([model.alphas_cumprod_prev[0:1], model.alphas_cumprod])
-    seq, seq_next = [250, 500, 750], [-1, 250, 500]
-    eng = sampler.LeapfrogEngine(algo.score, op, None, seq, seq_next, device, chunk=args.chunk, alpha_table=table,
-                                 image_map=model.differentiable_decode_first_stage)
-    lo = rank * B
-    zshape = (B, model.channels, ZDIM, ZDIM)
-    x = K.randn_philox(zshape, seed, lo, 0, device=device)
-    p = K.randn_philox(zshape, seed, lo, 1, device=device)
-    x_true = K.randn_philox((B, CH, DIM, DIM), seed, lo, 2, device=device).clamp_(-1, 1)
-    y = op.H(x_true) + (2 * SIGMA0_CLI) * torch.randn(B, op.M, device=device,
-                                                       generator=torch.Generator(device=device).manual_seed(seed + lo))
-    eps = torch.full((B,), 0.1, dtype=torch.float64, device=device)            # main_sampling_latent.py:828-830 default
-    sig = torch.full((B,), 0.5, dtype=torch.float64, device=device)            # --sigma_y default, :832
-    ws = K.leapfrog_ws(B, x[0].numel(), device)
+    lp = latent_problem(device, B, rank * B, args.chunk)
+    model, op, algo, table, seq, seq_next, eng = (lp[k] for k in ('model', 'op', 'algo', 'table', 'seq', 'seq_next', 'eng'))
+    x, p, y, eps, sig, ws, zshape = (lp[k] for k in ('x', 'p', 'y', 'eps', 'sig', 'ws', 'zshape'))
     args.chunk = args.chunk or B
     eng = settle_score_chunk(eng, lambda c: sampler.LeapfrogEngine(algo.score, op, None, seq, seq_next, device, chunk=c, alpha_table=table,
                                                                   image_map=model.differentiable_decode_first_stage),
@@ -610,10 +631,14 @@ def main():
             by_deg = {}
             for deg in ('sr4', 'deblur_aniso'):
                 by_deg[deg] = degradation_leg(device, deg, prob['model'], B, args.chunk)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline()
         if not args.kernel_only:
             single = single_chain_rate(eng, x, p, y, eps, sig, with_graph=(world == 1))
+        if by_deg is not None and not args.tiny_score:
+            prob['algo'] = prob['model'] = eng = None                       # the pixel-space network is done
+            torch.cuda.empty_cache()
+            by_deg['hmc_latent'] = latent_leg(device)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
         line = {
             'metric': f'HMC leapfrog chain-steps/sec (256x256x3 FFHQ {args.deg}, U-Net score in the loop)',
             'value': None if value is None else round(value, 3), 'unit': 'chain-steps/s', 'n_gpus': world,
