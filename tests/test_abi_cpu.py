@@ -77,6 +77,15 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.nhmc_bias_add2(a16, a16, a16, a16, 1, 8, 6, null) == 3                                      # hw % 4
     assert lib.nhmc_ddim_mix_bwd_inpaint_px(a16, a16, 6, a16, a16, a16, a16, a16, 10, a16, a16, 0, a16, 1, 3, 100, null) == 3  # hw % 32
     assert lib.nhmc_inpaint_px_tiles(3, 65536) == 3 * 64 and lib.nhmc_gn_splits(32, 128, 32, 65536) >= 1
+    assert lib.nhmc_spectral_project(a16, a16, a16, a16, a16, 1, 3, 48, null) == 3                         # dim % 32
+    assert lib.nhmc_spectral_project(a16, null, a16, a16, a16, 1, 3, 64, null) == 1
+    assert lib.nhmc_data_spectral_proj(a16, a16, a16, a16, 1, a16, a16, a16, 1, 3, 48, null) == 3
+    assert lib.nhmc_data_spectral_proj(a16, null, a16, a16, 1, a16, a16, a16, 1, 3, 64, null) == 1          # needs y_proj
+    assert lib.nhmc_data_spectral_proj_vjp(a16, a16, a16, a16, a16, a16, 5, a16, a16, a16, a16, a16, a16, 1, 3, 64, null) == 3  # e_channels
+    assert lib.nhmc_data_spectral_proj_vjp(a16, a16, a16, a16, a16, a16, 6, a16, a16, P(0x1004), a16, a16, a16, 1, 3, 64, null) == 2  # alignment
+    w5 = (ctypes.c_float * 5)(0.5, 0.5, 0.5, 0.0, -1.0)
+    assert lib.nhmc_color_Ht(a16, ctypes.cast(w5, P), 1, a16, 1, 3, 64, null) == 3                         # H^+ with a zero singular value
+    assert lib.nhmc_color_Ht(a16, ctypes.cast(w5, P), 0, a16, 1, 5, 64, null) == 3                         # channels > 4
 
 
 def test_no_cpu_fallback_in_the_python_binding():
