@@ -235,9 +235,10 @@ class Deblurring2D(H_functions):
 
     def _obs(self, y, shape):
         y = y.reshape(shape)
-        if not y.is_contiguous():
-            y = y.contiguous()
-        return self.project_observation(y) if self.projected else y
+        if y.is_contiguous():
+            return self.project_observation(y) if self.projected else y
+        y = y.contiguous()                                          # a temporary: projected afresh, never cached
+        return K.spectral_project(y, self._f(0), self._f(1)) if self.projected else y
 
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
         return K.data_spectral(xt, self._obs(y, xt.shape), self.factors, self.Dmap, apply_clip, loss_out=loss_out,
