@@ -225,3 +225,47 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     nerr = float((flat.double().norm(dim=1) - T(g['out_norm'])).abs().max() / T(g['out_norm']).max())
     print(f'returned images: probes rel err {err:.2e}, norms rel err {nerr:.2e}')
     assert err < 1e-4 and nerr < 1e-5
+
+
+def test_four_reference_runs_as_four_chains_of_one_call(golden, tiny_score):
+    """The reference is batch-1 (main_sampling.py:719 raises for n > 1); the build's engine runs B chains with per-chain
+    sigma_y / epsilon schedules, accept bookkeeping and activity masks.  G14's inpainting run and three more runs of the
+    same problem under other seeds (G17, oracle/gen_golden_hmc_batch.py) are replayed TOGETHER as four chains of one
+    `hmc_chains` call, each on its own tape: every chain must make its reference run's decisions and return that run's
+    images, although the chains accept, anneal and finish at different iterations (204 / ... trajectories)."""
+    import nhmc.operators as ops
+    from nhmc import plugin, sampler
+    g0 = golden('g14_hmc_f64_inpaint_32.npz')
+    runs = [g0] + [golden(f'g17_hmc_f64_inpaint_32_s{s}.npz') for s in (1001, 1002, 1003)]
+    dev, B = torch.device('cuda'), 4
+    tapes, plays, accs, lens = [], [], [], []
+    for g in runs:
+        n = len(g['u'])
+        torch.manual_seed(int(g['seed']))
+        P, U = [], []
+        for _ in range(n):
+            P.append(torch.randn(1, 3, 32, 32))
+            U.append(float(torch.rand(1)))
+        assert np.array_equal(np.array(U), g['u']) and np.array_equal(P[0].numpy(), g['p0']) and np.array_equal(P[-1].numpy(), g['p_last'])
+        prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
+        acc = g['u'] < prob
+        assert int(acc.sum()) == 100
+        plays.append(np.where(np.abs(g['u'] - prob) < BAND, np.where(acc, 0.0, 1.0), g['u']).astype(np.float32))
+        tapes.append(P); accs.append(acc); lens.append(n)
+    assert len(set(lens)) > 1                                         # the chains do finish at different iterations
+    pad = lambda seq, it: seq[min(it, len(seq) - 1)]
+    noise = sampler.TapeNoise(lambda it: torch.cat([pad(P, it) for P in tapes]),
+                              lambda it: torch.tensor([float(pad(u, it)) for u in plays]))
+    op = ops.Inpainting(3, 32, T(g0['missing']), dev)
+    algo = plugin.HMC(F64Score(tiny_score).to(dev), op, float(g0['sigma_0']))
+    opt = types.SimpleNamespace(tau=float(g0['tau']), epsilon=float(g0['epsilon']), m=float(g0['m']), sigma_0=float(g0['sigma_0']), quiet=True)
+    rep = lambda a: T(a).repeat(B, *([1] * (a.ndim - 1))).to(dev)
+    res = sampler.hmc_chains(rep(g0['x']), osched.betas_fp32().to(dev), SEQ, SEQ_NEXT, algo, opt, rep(g0['y_0']), op, rep(g0['x_orig']),
+                             noise=noise, collect_trace=True)
+    assert res.iters == max(lens)
+    for c, g in enumerate(runs):
+        got = np.array([bool(r['accept'][c]) for r in res.trace[:lens[c]]])
+        assert np.array_equal(got, accs[c]), (c, np.nonzero(got != accs[c])[0][:5])
+        err = rel(res.samples[c], T(g['out']))
+        print(f'chain {c}: {lens[c]} trajectories, returned images rel err {err:.2e}')
+        assert err < 1e-4
