@@ -176,7 +176,7 @@ int nhmc_sr_Ht(const float* y, float* x, int ratio, float scale, int n_chains, i
 
 /* Colorization (Hfuncs.py:655-695).  w: HOST array of channels + 2 floats (channels <= 4; passed by value to the
  * kernel): the SVD (u, s, V) of the 1 x C grey row as the reference holds it -- V[0,0] .. V[C-1,0], s, U[0,0].
- *   H x = u * (s * ((v_0 x_0 + v_1 x_1) + v_2 x_2)),  H^T y = v_c * (s * (u * y)),  H^+ y = v_c * ((u * y) / s),
+ *   H x = u * (s * ((v_0 x_0 + v_1 x_1) + v_2 x_2)),  H^T y = v_c * (s * (u * y)),  H^+ y = v_c * ((u * y) * (1 / s)),
  * each product and sum rounded in this order (torch's CPU ops on the reference's composition: same bits).
  * loss partials: nhmc_color_tiles(hw) per chain. */
 int nhmc_color_tiles(int64_t hw);

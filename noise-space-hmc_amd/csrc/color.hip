@@ -4,7 +4,7 @@
 //     H x   = u * (s * ((v_0 x_0 + v_1 x_1) + v_2 x_2))        (Vt: a [C x C] @ [C x 1] matmul per pixel, torch sums
 //                                                               its K = C products left to right, each rounded; :673-680,
 //                                                               then singulars *, then U)
-//     H^T y = v_c * (s * (u * y)),     H^+ y = v_c * ((u * y) / s)                     (:65-90 composed with :682-695)
+//     H^T y = v_c * (s * (u * y)),     H^+ y = v_c * ((u * y) * (1 / s))               (:65-90 composed with :682-695)
 //     d loss / d x_c = v_c * (s * (u * (-(2 r))))               (autograd of the line above, in its order)
 // in exactly these roundings, so the operator, the data term and its gradient reproduce torch's CPU bits (G15 replay).
 // One thread owns a float4 of pixels and reads the C channel planes at the same offset: coalesced 16-byte accesses,
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_color(const float4* __restrict__
       const float yv[4] = {y.x, y.y, y.z, y.w};
       float t[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t[k] = MODE == 2 ? wt.s * (wt.u * yv[k]) : (wt.u * yv[k]) / wt.s;
+      for (int k = 0; k < 4; ++k) t[k] = MODE == 2 ? wt.s * (wt.u * yv[k]) : (wt.u * yv[k]) * (1.0f / wt.s);   // :80-90 multiplies by 1 / s
       for (int c = 0; c < channels; ++c) {
         float4 o;
         o.x = wt.w[c] * t[0]; o.y = wt.w[c] * t[1]; o.z = wt.w[c] * t[2]; o.w = wt.w[c] * t[3];

@@ -168,7 +168,7 @@ class ColorRef:
     0.3333]]) (:660-661) and v = V[:, 0]:  Vt (:673-680) is a [3 x 3] @ [3 x 1] matmul per pixel, whose K = 3 products
     torch's CPU kernel rounds one by one and sums left to right; H (:65-71) then multiplies by the singular value and
     by U[0,0]:  H x = u * (s * ((v0 x0 + v1 x1) + v2 x2)).  H^T y = v_c * (s * (u * y)) (:73-78 with the zero padding
-    of :691-695 contributing exact zeros), H^+ y = v_c * ((u * y) / s) (:80-90).  Reproduces the reference's whole
+    of :691-695 contributing exact zeros), H^+ y = v_c * ((u * y) * (1 / s)) (:80-90).  Reproduces the reference's whole
     `hmc()` run bit for bit (G15 color)."""
 
     def __init__(self, img_dim):
@@ -189,7 +189,7 @@ class ColorRef:
 
     def H_pinv(self, y):
         B = y.shape[0]
-        t = (self.u * y.reshape(B, 1, -1)) / self.s
+        t = (self.u * y.reshape(B, 1, -1)) * (1 / self.s)             # :86-88 multiplies by the reciprocal
         return (self.v.view(1, 3, 1) * t).reshape(B, -1)
 
 

@@ -35,4 +35,5 @@ def test_cs_data_term(dim, ratio, B):
     assert torch.equal(op.Ht(y.cuda()).cpu(), ref.Ht(y))
     loss_ref, g_ref = hmc_ref.data_term(xt, ref, y)
     loss, g = op.data_term(xt.cuda(), y.cuda(), apply_clip=True)
-    assert rel(loss, loss_ref) < 2e-6 and rel(g, g_ref) < 2e-6
+    # the adjoint runs its butterfly stages in autograd's (descending) order: the oracle's gradient, bit for bit
+    assert rel(loss, loss_ref) < 2e-6 and torch.equal(g.cpu(), g_ref)

@@ -21,11 +21,12 @@ def test_color_and_gauss_against_reference_outputs(golden, dim):
     x = T(g['x']).cuda()
     gauss = operators.Deblurring2D.from_factors(T(g['gauss_U']), T(g['gauss_U']), T(g['gauss_V']), T(g['gauss_V']),
                                                 T(g['gauss_D']), 'cuda')
-    for name, op, tol in (('color', operators.Colorization(dim, 'cuda'), 2e-6), ('gauss', gauss, 2e-5)):
+    for name, op, tol in (('color', operators.Colorization(dim, 'cuda'), 0.0), ('gauss', gauss, 2e-5)):
         y = T(g[f'{name}_y']).cuda()
-        assert rel(op.H(x), T(g[f'{name}_Hx'])) < tol, name
-        assert rel(op.Ht(y), T(g[f'{name}_Hty'])) < tol, name
-        assert rel(op.H_pinv(y), T(g[f'{name}_Hpinvy'])) < 5 * tol, name
+        # colorization: V^T, s and U applied in the reference's rounding order -> the reference's bits (tol 0)
+        assert rel(op.H(x), T(g[f'{name}_Hx'])) <= tol, name
+        assert rel(op.Ht(y), T(g[f'{name}_Hty'])) <= tol, name
+        assert rel(op.H_pinv(y), T(g[f'{name}_Hpinvy'])) <= 5 * tol, name
 
 
 @pytest.mark.parametrize('dim,B', [(32, 3), (256, 2)])
@@ -37,7 +38,7 @@ def test_color_data_term(dim, B):
     y = torch.randn(B, ref.M, generator=g_)
     loss_ref, g_ref = hmc_ref.data_term(xt, ref, y)
     loss, g = op.data_term(xt.cuda(), y.cuda(), apply_clip=True)
-    assert rel(loss, loss_ref) < 2e-6 and rel(g, g_ref) < 2e-6
+    assert rel(loss, loss_ref) < 2e-6 and torch.equal(g.cpu(), g_ref)          # the gradient in autograd's rounding order
 
 
 def test_deblur_gauss_constructor_builds_the_reference_operator(golden):
