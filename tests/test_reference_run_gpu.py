@@ -10,8 +10,10 @@ returned: same accept decisions, same 20 reconstructed images within north_star'
 Accept-ambiguity band: H is a sum of ~1e3..1e4 in fp32 whose last bits differ between the reference's fp32 torch sums
 and the kernels' fp64 partials, so a decision whose uniform lies within BAND of the accept probability is not
 determined by the algorithm.  Those iterations (reported) are replayed with the uniform moved to 0 / 1, i.e. with the
-reference's own decision; every other decision must come out of the GPU's own energies."""
-import copy
+reference's own decision; every other decision must come out of the GPU's own energies.
+
+Further down: G15 (the six remaining operators, same recipe), G16 (inpaint / sr4 / aniso at 256 x 256, BASELINE
+configs[0] geometry) and G17 (four reference runs replayed together as four chains of one call)."""
 import types
 
 import numpy as np
