@@ -648,7 +648,8 @@ def main():
             'config': {'workload': ('BASELINE configs[1]' if args.deg == 'inpaint_random' else 'BASELINE configs[1] with another degradation') +
                                    f': FFHQ 256x256 {args.deg} sigma_0=0.05 tau=1.0 eps=0.05 '
                                    f'timesteps=3, {B} chains per GPU, ' +
-                                   ('REHEARSAL with a 32-channel U-Net (not the metric)' if args.tiny_score else 'FFHQ U-Net architecture random-init fp32'),
+                                   ('REHEARSAL with a 32-channel U-Net (not the metric)' if args.tiny_score else 'FFHQ U-Net architecture random-init fp32') +
+                                   (' -- REHEARSAL: the ranks share ONE GPU over gloo (not a multi-GPU measurement)' if args.rehearse_shared_gpu else ''),
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
             'roofline': roofline, 'hot_path_only': hot, 'hot_path_kernels': ktable, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
