@@ -385,10 +385,13 @@ int nhmc_gn_splits(int n, int channels, int groups, int64_t hw);
 int nhmc_gn_act_fwd(const float* x, const float* gamma, const float* beta, const float* film, int64_t film_stride,
                     const float* pre, int64_t pre_stride, float eps, int act, float* y, double* ws, int splits,
                     int n, int channels, int groups, int64_t hw, nhmc_stream_t stream);
+/* dx_add (optional, same shape as x, must not alias dx): a second gradient of x -- in a ResBlock the block input feeds the
+ * GroupNorm AND the skip path -- added to the result in the same pass: dx = fl(dx_groupnorm) + dx_add, the bits of
+ * autograd's separate accumulation add. */
 int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* film,
                     int64_t film_stride, const float* pre, int64_t pre_stride, float eps, int act,
-                    const double* fwd_ws, float* dx, double* ws, int splits, int n, int channels, int groups,
-                    int64_t hw, nhmc_stream_t stream);
+                    const double* fwd_ws, const float* dx_add, float* dx, double* ws, int splits, int n, int channels,
+                    int groups, int64_t hw, nhmc_stream_t stream);
 /* out = (h + bias_c) + other, [n][channels][hw]: a convolution's bias folded into the residual add that follows it
  * (unet_ffhq.py:321).  Its backward is the identity towards both h and other. */
 int nhmc_bias_add2(const float* h, const float* bias, const float* other, float* out, int n, int channels,

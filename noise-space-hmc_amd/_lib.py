@@ -72,7 +72,7 @@ SIGNATURES = {
     'nhmc_vq_nearest': (I, [P, P, P, P, I, I, I64, I, P]),
     'nhmc_gn_splits': (I, [I, I, I, I64]),
     'nhmc_gn_act_fwd': (I, [P, P, P, P, I64, P, I64, F, I, P, P, I, I, I, I, I64, P]),
-    'nhmc_gn_act_bwd': (I, [P, P, P, P, P, I64, P, I64, F, I, P, P, P, I, I, I, I, I64, P]),
+    'nhmc_gn_act_bwd': (I, [P, P, P, P, P, I64, P, I64, F, I, P, P, P, P, I, I, I, I, I64, P]),
     'nhmc_bias_add2': (I, [P, P, P, P, I, I, I64, P]),
     'nhmc_psnr': (I, [P, P, P, P, I, I64, P]),
     'nhmc_randn_philox': (I, [P, U64, U32, U32, F, I, I64, P]),

@@ -84,10 +84,12 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_stats(const float4* __restric
   if (threadIdx.x == 0) { ws[((int64_t)bg * a.splits + split) * 2] = v[0]; ws[((int64_t)bg * a.splits + split) * 2 + 1] = v[1]; }
 }
 
+// BWD, `acc` (optional): a second gradient of x -- the block input also feeds the skip path -- added to the result here
+// (fl(dx) + acc, what autograd's accumulation would compute in a pass of its own: 2 reads + 1 write saved).
 template <bool BWD>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_apply(const float4* __restrict__ x, const float4* __restrict__ dy,
                                                          const double* __restrict__ fwd_ws, const double* __restrict__ bwd_ws,
-                                                         GnArgs a, float4* __restrict__ out) {
+                                                         GnArgs a, float4* __restrict__ out, const float4* __restrict__ acc) {
   const int bg = blockIdx.y;
   const int b = bg / a.G, g = bg % a.G, cpg = a.C / a.G;
   const int64_t n4 = (int64_t)cpg * a.hw / 4, base = (int64_t)bg * n4;
@@ -134,6 +136,10 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_gn_apply(const float4* __restric
         float du = de[c];
         if (a.act) { const float u = xh * ga + be, sg = gn_sigmoid(u); du = du * (sg * (1.0f + u * (1.0f - sg))); }
         oe[c] = rstd * ((du * ga - m0) - xh * m1);
+      }
+      if (acc) {
+        const float4 av = acc[base + q];
+        o.x = o.x + av.x; o.y = o.y + av.y; o.z = o.z + av.z; o.w = o.w + av.w;
       }
     }
     out[base + q] = o;
@@ -190,17 +196,19 @@ extern "C" int nhmc_gn_act_fwd(const float* x, const float* gamma, const float* 
               (const float4*)nullptr, (const double*)nullptr, a, ws);
   if ((rc = nhmc_launch_status())) return rc;
   NHMC_LAUNCH(k_gn_apply<false>, dim3((unsigned)((n4 + NHMC_BLOCK * 2 - 1) / (NHMC_BLOCK * 2)), (unsigned)(n * groups)),
-              dim3(NHMC_BLOCK), 0, st, (const float4*)x, (const float4*)nullptr, ws, (const double*)nullptr, a, (float4*)y);
+              dim3(NHMC_BLOCK), 0, st, (const float4*)x, (const float4*)nullptr, ws, (const double*)nullptr, a, (float4*)y,
+              (const float4*)nullptr);
   return nhmc_launch_status();
 }
 
 extern "C" int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* film,
                                int64_t film_stride, const float* pre, int64_t pre_stride, float eps, int act,
-                               const double* fwd_ws, float* dx, double* ws, int splits, int n, int channels, int groups,
-                               int64_t hw, nhmc_stream_t stream) {
+                               const double* fwd_ws, const float* dx_add, float* dx, double* ws, int splits, int n,
+                               int channels, int groups, int64_t hw, nhmc_stream_t stream) {
   int rc = gn_check(x, gamma, beta, n, channels, groups, hw, splits);
   if (rc) return rc;
-  if (!dy || !fwd_ws || !dx || !ws || !nhmc_aligned16(dy) || !nhmc_aligned16(dx)) return NHMC_ERR_ARG;
+  if (!dy || !fwd_ws || !dx || !ws || !nhmc_aligned16(dy) || !nhmc_aligned16(dx) || !nhmc_aligned16(dx_add) || dx_add == dx)
+    return NHMC_ERR_ARG;
   const GnArgs a{gamma, beta, film, film_stride, pre, pre_stride, channels, groups, hw, eps, act, splits};
   const int64_t n4 = (int64_t)(channels / groups) * hw / 4;
   hipStream_t st = nhmc_s(stream);
@@ -208,7 +216,7 @@ extern "C" int nhmc_gn_act_bwd(const float* x, const float* dy, const float* gam
               (const float4*)dy, fwd_ws, a, ws);
   if ((rc = nhmc_launch_status())) return rc;
   NHMC_LAUNCH(k_gn_apply<true>, dim3((unsigned)((n4 + NHMC_BLOCK * 2 - 1) / (NHMC_BLOCK * 2)), (unsigned)(n * groups)),
-              dim3(NHMC_BLOCK), 0, st, (const float4*)x, (const float4*)dy, fwd_ws, ws, a, (float4*)dx);
+              dim3(NHMC_BLOCK), 0, st, (const float4*)x, (const float4*)dy, fwd_ws, ws, a, (float4*)dx, (const float4*)dx_add);
   return nhmc_launch_status();
 }
 

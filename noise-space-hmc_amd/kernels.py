@@ -657,15 +657,19 @@ def gn_act_fwd(x, gamma, beta, groups, eps, act, film=None, pre=None):
     return y, ws, splits
 
 
-def gn_act_bwd(x, dy, gamma, beta, groups, eps, act, film, fwd_ws, splits, pre=None):
-    """Input gradient of gn_act_fwd (parameters, FiLM and pre-bias terms are constants of the path)."""
+def gn_act_bwd(x, dy, gamma, beta, groups, eps, act, film, fwd_ws, splits, pre=None, add=None):
+    """Input gradient of gn_act_fwd (parameters, FiLM and pre-bias terms are constants of the path).
+    add (optional, x's shape): a second gradient of x, added in the same pass."""
     lib = _lib.load()
     B, Cc, hw, stride, pstride = _gn_shape(x, gamma, groups, film, pre)
     ws = torch.empty(B * groups * splits * 2, dtype=torch.float64, device=x.device)
     dx = torch.empty_like(x)
+    if add is not None and (add.shape != x.shape or add.data_ptr() == dx.data_ptr()):
+        raise _lib.NhmcError('gn_act_bwd: `add` must have the shape of x')
     rc = lib.nhmc_gn_act_bwd(_p(x, torch.float32, 'x'), _p(dy, torch.float32, 'dy'), _p(gamma, torch.float32, 'gamma'),
                              _p(beta, torch.float32, 'beta'), _ptr(film), stride, _ptr(pre), pstride, float(eps), int(act),
-                             _p(fwd_ws, torch.float64), _p(dx), _p(ws), splits, B, Cc, groups, hw, _stream())
+                             _p(fwd_ws, torch.float64), _p(add, torch.float32, 'add') if add is not None else _ptr(None), _p(dx),
+                             _p(ws), splits, B, Cc, groups, hw, _stream())
     _lib.check(rc, 'nhmc_gn_act_bwd')
     return dx
 

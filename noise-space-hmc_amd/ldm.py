@@ -31,7 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import kernels as K
-from .unet import AttentionBlock, Stage, _BiasAdd2, conv_nobias, fused_glue, group_norm_act, sinusoid, sinusoid_freqs
+from .unet import AttentionBlock, Stage, _BiasAdd2, conv_nobias, fused_glue, group_norm_act, group_norm_act_fork, sinusoid, sinusoid_freqs
 
 # configs/config_ffhq_latent.yml:45-80
 FFHQ_LDM_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=(8, 4, 2),
@@ -175,7 +175,7 @@ class PlainResBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x):
-        h = group_norm_act(self.norm1, x, act_fn=_swish)                 # Normalize + x sigmoid(x)
+        h, x = group_norm_act_fork(self.norm1, x, act_fn=_swish)         # Normalize + x sigmoid(x); x goes on to the shortcut
         sc = self.nin_shortcut(x) if hasattr(self, 'nin_shortcut') else x
         if fused_glue(h, self.conv1.bias, self.conv2.bias):
             h = group_norm_act(self.norm2, conv_nobias(self.conv1, h), act_fn=_swish, pre=self.conv1.bias)

@@ -61,6 +61,35 @@ class _GroupNormAct(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+class _GroupNormActFork(torch.autograd.Function):
+    """_GroupNormAct with x itself as a second output, for a block whose input feeds the GroupNorm AND the skip path
+    (unet_ffhq.py:299-321: `h = self.in_layers(x)` ... `self.skip_connection(x) + h`).  The two gradients of x then meet
+    inside the backward kernel (dx = fl(dx_groupnorm) + dx_skip, the bits of autograd's accumulation) instead of in a
+    pass of their own."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, pre, groups, eps, act):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y, ws, splits = K.gn_act_fwd(xc, gamma, beta, groups, eps, act, film, pre)
+        ctx.save_for_backward(xc, gamma, beta, ws)
+        ctx.consts = (film, pre)
+        ctx.meta = (groups, eps, act, splits)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dx_skip):
+        xc, gamma, beta, ws = ctx.saved_tensors
+        groups, eps, act, splits = ctx.meta
+        film, pre = ctx.consts
+        if dy is None:
+            return dx_skip, None, None, None, None, None, None, None
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if dx_skip is not None and not dx_skip.is_contiguous():
+            dx_skip = dx_skip.contiguous()
+        dx = K.gn_act_bwd(xc, dy, gamma, beta, groups, eps, act, film, ws, splits, pre, add=dx_skip)
+        return dx, None, None, None, None, None, None, None
+
+
 class _BiasAdd2(torch.autograd.Function):
     """(h + bias_c) + other in one pass; the gradient reaches h and other unchanged."""
 
@@ -97,6 +126,14 @@ def group_norm_act(gn, x, act=True, film=None, act_fn=F.silu, pre=None):
         scale, shift = film.reshape(film.shape + (1,) * (x.dim() - 2)).chunk(2, dim=1)
         h = h * (1 + scale) + shift
     return act_fn(h) if act else h
+
+
+def group_norm_act_fork(gn, x, act=True, act_fn=F.silu):
+    """(group_norm_act(gn, x), x) for a block input that also feeds the block's skip path: on the fused kernels the
+    second element is an alias of x whose gradient is added inside the GroupNorm's backward kernel."""
+    if x.requires_grad and torch.is_grad_enabled() and fused_glue(x, gn.weight, gn.bias):
+        return _GroupNormActFork.apply(x, gn.weight, gn.bias, None, None, gn.num_groups, gn.eps, act)
+    return group_norm_act(gn, x, act=act, act_fn=act_fn), x
 
 
 def conv_nobias(conv, x):
@@ -156,7 +193,7 @@ class ResBlock(nn.Module):
         self.skip_connection = nn.Identity() if out_ch == ch else nn.Conv2d(ch, out_ch, 1)
 
     def forward(self, x, emb):
-        h = group_norm_act(self.in_layers[0], x)                         # GroupNorm + SiLU
+        h, x = group_norm_act_fork(self.in_layers[0], x)                 # GroupNorm + SiLU; x goes on to the skip path
         if self.resample:
             h, x = self.h_upd(h), self.x_upd(x)
         conv1, conv2, film = self.in_layers[2], self.out_layers[3], self.emb_layers(emb)

@@ -73,7 +73,8 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.nhmc_vq_nearest(a16, null, a16, null, 1, 3, 4096, 8192, null) == 1
     assert lib.nhmc_gn_act_fwd(a16, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, 1, 1, 64, 32, 9, null) == 3   # hw % 4
     assert lib.nhmc_gn_act_fwd(a16, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, 1, 1, 48, 32, 64, null) == 3  # C % G
-    assert lib.nhmc_gn_act_bwd(a16, null, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, a16, 1, 1, 64, 32, 64, null) == 1
+    assert lib.nhmc_gn_act_bwd(a16, null, a16, a16, null, 0, null, 0, 1e-5, 1, a16, null, a16, a16, 1, 1, 64, 32, 64, null) == 1
+    assert lib.nhmc_gn_act_bwd(a16, a16, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, a16, a16, 1, 1, 64, 32, 64, null) == 1   # dx_add aliases dx
     assert lib.nhmc_bias_add2(a16, a16, a16, a16, 1, 8, 6, null) == 3                                      # hw % 4
     assert lib.nhmc_ddim_mix_bwd_inpaint_px(a16, a16, 6, a16, a16, a16, a16, a16, 10, a16, a16, 0, a16, 1, 3, 100, null) == 3  # hw % 32
     assert lib.nhmc_inpaint_px_tiles(3, 65536) == 3 * 64 and lib.nhmc_gn_splits(32, 128, 32, 65536) >= 1

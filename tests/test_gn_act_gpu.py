@@ -107,6 +107,33 @@ def test_pre_bias_and_bias_residual_add(per_sample):
     assert torch.equal(gh, dy) and torch.equal(go, dy)
 
 
+def test_block_input_fork_adds_the_skip_gradient_inside_the_backward_kernel():
+    """x feeds GroupNorm + SiLU and, unchanged, the skip path: the fork op returns an alias of x whose gradient is added
+    inside the GroupNorm backward kernel -- the same bits as autograd's separate accumulation of the two gradients."""
+    from nhmc import unet
+    g = torch.Generator().manual_seed(8)
+    B, C, H = 2, 64, 32
+    gn = torch.nn.GroupNorm(32, C).cuda().requires_grad_(False)
+    gn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g).cuda())
+    x = torch.randn(B, C, H, H, generator=g).cuda()
+    dy, ds = torch.randn(B, C, H, H, generator=g).cuda(), torch.randn(B, C, H, H, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    ya = unet.group_norm_act(gn, xa)
+    (ga,) = torch.autograd.grad((ya * dy).sum() + (xa * ds).sum(), xa)                 # autograd adds the two gradients
+    xb = x.clone().requires_grad_(True)
+    yb, xs = unet.group_norm_act_fork(gn, xb)
+    assert type(yb.grad_fn).__name__.startswith('_GroupNormActFork') and xs.data_ptr() == xb.data_ptr()
+    (gb,) = torch.autograd.grad((yb * dy).sum() + (xs * ds).sum(), xb)
+    assert torch.equal(yb, ya) and torch.equal(gb, ga)
+    yc, _ = unet.group_norm_act_fork(gn, xb)                                            # skip path unused
+    (gc,) = torch.autograd.grad((yc * dy).sum(), xb)
+    (gd,) = torch.autograd.grad((unet.group_norm_act(gn, xa) * dy).sum(), xa)
+    assert torch.equal(gc, gd)
+    with torch.no_grad():
+        yn, xn = unet.group_norm_act_fork(gn, x)
+    assert xn is x and torch.equal(yn, ya)
+
+
 def test_resblocks_with_and_without_the_fused_glue_agree():
     """A ResBlock of each network family (FFHQ scale-shift block, LDM additive-embedding block, VQ decoder block):
     fused glue vs NHMC_FUSED_GN=0, forward and input gradient."""
