@@ -43,7 +43,7 @@ enum {
   NHMC_ERR_LAUNCH = 4  /* hipGetLastError() after launch != hipSuccess */
 };
 
-#define NHMC_ABI_VERSION 1
+#define NHMC_ABI_VERSION 2
 int nhmc_abi_version(void);
 const char* nhmc_status_string(int status);
 /* HIP's message for the last NHMC_ERR_LAUNCH raised on the calling thread (diagnostics only). */
@@ -77,6 +77,38 @@ int nhmc_leapfrog_fused(int mode, float* x, float* p, const float* g, const floa
 int nhmc_leapfrog_first(const float* x_in, float* x_out, float* p, const float* g, const float* g2,
                         const double* eps, const double* sigma_y, double m_inv,
                         int n_chains, int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gradient cache: one decode + gradient per leapfrog step, none for the first half step.
+ *
+ * The reference evaluates the decode, loss and gradient at the accepted position x at the top of every outer
+ * iteration (main_sampling.py:693-695), although that point was already evaluated: by the previous iteration's last
+ * leapfrog step if its proposal was accepted (x is that proposal, :709-711,731), by the previous iteration's own
+ * :693-695 if it was rejected (x did not move).  Loss and gradient do not depend on sigma_y / eps (those enter inside
+ * the update), so the values are identical and reusing them changes no bit while removing 1 of L+1 score-network
+ * ladders per trajectory.
+ *
+ * Layout: g_pair = float[2][pair_stride] (pair_stride >= n_chains_total * n_elem, % 4 == 0), slot s of chain c at
+ * g_pair + s*pair_stride + c*n_elem, holding the SUMMED gradient g + g2 (the fp32 add the update kernels perform
+ * first anyway); loss_pair = double[2][loss_stride]; sel = int32[n_chains], the slot that belongs to the accepted
+ * position.  All pointers are those of the launch's first chain (chunk views just offset them).
+ *   nhmc_grad_cache_store        slot (sel ^ flip) <- (g + g2, loss)          (the once-per-run evaluation at x0)
+ *   nhmc_leapfrog_first_cached   NHMC_LF_FIRST (out of place) with g read from slot sel
+ *   nhmc_leapfrog_last_cached    NHMC_LF_LAST, and slot 1 - sel <- (g + g2, loss) of the end point
+ *   nhmc_hamiltonian_cached      nhmc_hamiltonian with loss = loss_pair[sel]
+ *   nhmc_grad_cache_flip         sel ^= accept                                 (after the Metropolis test)
+ * ---------------------------------------------------------------------------------- */
+int nhmc_grad_cache_store(const float* g, const float* g2, const double* loss, float* g_pair, double* loss_pair,
+                          const int32_t* sel, int flip, int64_t pair_stride, int64_t loss_stride,
+                          int n_chains, int64_t n_elem, nhmc_stream_t stream);
+int nhmc_leapfrog_first_cached(const float* x_in, float* x_out, float* p, const float* g_pair, const int32_t* sel,
+                               int64_t pair_stride, const double* eps, const double* sigma_y, double m_inv,
+                               int n_chains, int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
+int nhmc_leapfrog_last_cached(float* x, float* p, const float* g, const float* g2, float* g_pair, const int32_t* sel,
+                              int64_t pair_stride, const double* loss, double* loss_pair, int64_t loss_stride,
+                              const double* eps, const double* sigma_y, double m_inv,
+                              int n_chains, int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
+int nhmc_grad_cache_flip(const int32_t* accept, int32_t* sel, int n_chains, nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a9-a10  DDIM mix, forward               algos/unconditional.py:17-28, main_sampling.py:709
@@ -284,6 +316,10 @@ int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* At, 
 int nhmc_hamiltonian(const double* sums_ws, int tiles, const double* loss, const double* sigma_y,
                      double m_inv, float* H_out, double* terms, int n_chains,
                      nhmc_stream_t stream);
+/* the same with the loss taken from the gradient cache: loss_pair[sel[chain]*loss_stride + chain] */
+int nhmc_hamiltonian_cached(const double* sums_ws, int tiles, const double* loss_pair, const int32_t* sel,
+                            int64_t loss_stride, const double* sigma_y, double m_inv, float* H_out, double* terms,
+                            int n_chains, nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a6  Metropolis test, per chain, on the device (no host sync)   main_sampling.py:718-720

@@ -20,6 +20,11 @@ SIGNATURES = {
     'nhmc_leapfrog_ws_bytes': (SZ, [I, I64]),
     'nhmc_leapfrog_fused': (I, [I, P, P, P, P, P, P, D, I, I64, P, P]),
     'nhmc_leapfrog_first': (I, [P, P, P, P, P, P, P, D, I, I64, P, P]),
+    'nhmc_grad_cache_store': (I, [P, P, P, P, P, P, I, I64, I64, I, I64, P]),
+    'nhmc_leapfrog_first_cached': (I, [P, P, P, P, P, I64, P, P, D, I, I64, P, P]),
+    'nhmc_leapfrog_last_cached': (I, [P, P, P, P, P, P, I64, P, P, I64, P, P, D, I, I64, P, P]),
+    'nhmc_grad_cache_flip': (I, [P, P, I, P]),
+    'nhmc_hamiltonian_cached': (I, [P, I, P, P, I64, P, D, P, P, I, P]),
     'nhmc_ddim_mix_fwd': (I, [P, P, I, P, P, I, P, P, P, I, I, I64, P]),
     'nhmc_ddim_map_back': (I, [P, P, P, P, I, I64, P]),
     'nhmc_ddim_mix_bwd': (I, [P, P, P, P, P, I, P, P, I, P, P, I, I, I, I64, P]),
@@ -81,6 +86,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2          # NHMC_ABI_VERSION of include/nhmc.h this binding was written against
 
 
 class NhmcError(RuntimeError):
@@ -108,7 +114,7 @@ def load():
         except AttributeError as exc:
             raise NhmcError(f'{LIB_PATH} does not export {name}; rebuild it') from exc
         fn.restype, fn.argtypes = res, args
-    if lib.nhmc_abi_version() != 1:
+    if lib.nhmc_abi_version() != ABI_VERSION:
         raise NhmcError('libnhmc ABI version mismatch; rebuild it')
     _lib = lib
     return lib

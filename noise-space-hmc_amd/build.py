@@ -19,8 +19,9 @@ ARCH = 'gfx950'
 
 # -ffp-contract=off: the elementwise kernels reproduce the reference's separate fp32 mul/add ops
 # (ATen issues them unfused); the MFMA GEMM file is unaffected (explicit intrinsics).
-FLAGS = ['-O3', '-std=c++17', f'--offload-arch={ARCH}', '-fPIC', '-shared', '-ffp-contract=off',
+FLAGS = ['-O3', '-std=c++17', f'--offload-arch={ARCH}', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function']
+OBJ = os.path.join(PKG, 'build')          # per-source objects (git- and gpurun-ignored): only changed files recompile
 
 
 def sources():
@@ -43,13 +44,38 @@ def hipcc():
     return exe
 
 
-def build(force=False, verbose=True):
+def _obj_stale(src, obj, common):
+    return not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in [src] + common)
+
+
+def build(force=False, verbose=True, jobs=4):
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + sources() + ['-o', LIB + '.tmp']
+    os.makedirs(OBJ, exist_ok=True)
+    common = glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(PKG), 'include', 'nhmc.h'),
+                                                     os.path.abspath(__file__)]
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        if force or _obj_stale(src, obj, common):
+            todo.append([hipcc()] + FLAGS + ['-c', src, '-o', obj])
+    running = []
+    while todo or running:
+        while todo and len(running) < jobs:
+            cmd = todo.pop(0)
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, proc = running.pop(0)
+        if proc.wait() != 0:
+            for _, other in running:
+                other.wait()
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}'] + objs + ['-o', LIB + '.tmp']
     if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print(' '.join(link), flush=True)
+    subprocess.run(link, check=True)
     os.replace(LIB + '.tmp', LIB)
     return LIB
 

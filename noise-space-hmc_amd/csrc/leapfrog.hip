@@ -13,12 +13,37 @@ namespace {
 
 // OOP (FIRST only): the position is read from xin and the proposal written to x, so the caller's accepted position
 // survives the trajectory without a copy (same traffic as in place: R xin, W x).
-template <int MODE, bool HAS_G2, int VPT, bool OOP = false>
+//
+// CACHED: the gradient cache of the sampler (two slots per chain; sel[chain] = slot that holds loss / gradient at the
+// chain's ACCEPTED position).  FIRST reads its gradient from slot sel (the previous trajectory already evaluated that
+// point: its LAST step if it was accepted, its FIRST step if not -- main_sampling.py:693-695 re-evaluates it); LAST
+// stores the summed gradient g (+ g2) and the loss of the end point into slot 1 - sel, where they wait for the accept
+// decision (nhmc_grad_cache_flip).  pair4 = distance between the two slots in float4 units.
+struct LfCache {
+  const int32_t* sel;       // [n_chains]
+  float4* g_pair;           // slot 0 base of this launch's first chain
+  int64_t pair4;
+  const double* loss_in;    // LAST: loss of the end point [n_chains]
+  double* loss_pair;        // LAST: slot 0 base of the loss cache
+  int64_t loss_stride;
+};
+
+template <int MODE, bool HAS_G2, int VPT, bool OOP = false, bool CACHED = false>
 __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
     const float4* __restrict__ xin, float4* __restrict__ x, float4* __restrict__ p, const float4* __restrict__ g,
     const float4* __restrict__ g2, const double* __restrict__ eps, const double* __restrict__ sigma_y,
-    double m_inv, int64_t n4, double* __restrict__ sums_ws) {
+    double m_inv, int64_t n4, double* __restrict__ sums_ws, LfCache cache = LfCache()) {
   const int chain = blockIdx.y;
+  float4* gsave = nullptr;
+  if (CACHED) {
+    const int s = cache.sel[chain] & 1;
+    if (MODE == NHMC_LF_FIRST) g = cache.g_pair + (int64_t)s * cache.pair4;
+    if (MODE == NHMC_LF_LAST) {
+      gsave = cache.g_pair + (int64_t)(1 - s) * cache.pair4;
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+        cache.loss_pair[(int64_t)(1 - s) * cache.loss_stride + chain] = cache.loss_in[chain];
+    }
+  }
   const double e = eps[chain], s = sigma_y[chain];
   const float kf = (float)(1.0 / (2.0 * (s * s)));   // 1/(2*sigma_y**2)
   const float ef = (float)e;                          // epsilon
@@ -72,6 +97,7 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_leapfrog(
     const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
     nhmc_stnt(&p[base + q], pv[i]);
     if (MODE != NHMC_LF_LAST) nhmc_stnt(&x[base + q], xv[i]);
+    if (CACHED && MODE == NHMC_LF_LAST) nhmc_stnt(&gsave[base + q], gv[i]);
   }
 
   if (MODE != NHMC_LF_MID) {
@@ -103,10 +129,10 @@ int launch(float* x, float* p, const float* g, const float* g2, const double* ep
   dim3 grid(tiles, (unsigned)n_chains), block(NHMC_BLOCK);
   if (g2)
     NHMC_LAUNCH((k_leapfrog<MODE, true, VPT>), grid, block, 0, st, (const float4*)nullptr, (float4*)x, (float4*)p,
-                (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv, n4, ws);
+                (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv, n4, ws, LfCache());
   else
     NHMC_LAUNCH((k_leapfrog<MODE, false, VPT>), grid, block, 0, st, (const float4*)nullptr, (float4*)x, (float4*)p,
-                (const float4*)g, (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws);
+                (const float4*)g, (const float4*)nullptr, eps, sigma_y, m_inv, n4, ws, LfCache());
   return nhmc_launch_status();
 }
 
@@ -149,10 +175,113 @@ extern "C" int nhmc_leapfrog_first(const float* x_in, float* x_out, float* p, co
   hipStream_t st = nhmc_s(stream);
   if (g2)
     NHMC_LAUNCH((k_leapfrog<NHMC_LF_FIRST, true, NHMC_VEC_PER_THREAD, true>), grid, block, 0, st, (const float4*)x_in,
-                (float4*)x_out, (float4*)p, (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv, n4, sums_ws);
+                (float4*)x_out, (float4*)p, (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv, n4, sums_ws, LfCache());
   else
     NHMC_LAUNCH((k_leapfrog<NHMC_LF_FIRST, false, NHMC_VEC_PER_THREAD, true>), grid, block, 0, st, (const float4*)x_in,
-                (float4*)x_out, (float4*)p, (const float4*)g, (const float4*)nullptr, eps, sigma_y, m_inv, n4, sums_ws);
+                (float4*)x_out, (float4*)p, (const float4*)g, (const float4*)nullptr, eps, sigma_y, m_inv, n4, sums_ws,
+                LfCache());
+  return nhmc_launch_status();
+}
+
+// ---- gradient cache (one decode per leapfrog step: the FIRST half step reuses the previous evaluation) ----------
+namespace {
+
+__global__ __launch_bounds__(NHMC_BLOCK) void k_grad_cache_store(const float4* __restrict__ g,
+                                                                 const float4* __restrict__ g2, LfCache cache, int flip,
+                                                                 int64_t n4) {
+  const int chain = blockIdx.y;
+  const int s = (cache.sel[chain] ^ flip) & 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) cache.loss_pair[(int64_t)s * cache.loss_stride + chain] = cache.loss_in[chain];
+  float4* dst = cache.g_pair + (int64_t)s * cache.pair4 + (int64_t)chain * n4;
+  const int64_t t0 = (int64_t)blockIdx.x * (NHMC_BLOCK * NHMC_VEC_PER_THREAD) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NHMC_VEC_PER_THREAD; ++i) {
+    const int64_t q = t0 + (int64_t)i * NHMC_BLOCK;
+    if (q >= n4) continue;
+    float4 v = nhmc_ldnt(&g[(int64_t)chain * n4 + q]);
+    if (g2) {
+      const float4 h = nhmc_ldnt(&g2[(int64_t)chain * n4 + q]);
+      v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+    }
+    nhmc_stnt(&dst[q], v);
+  }
+}
+
+__global__ void k_grad_cache_flip(const int32_t* __restrict__ accept, int32_t* __restrict__ sel, int n_chains) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_chains && accept[c]) sel[c] = (sel[c] ^ 1) & 1;
+}
+
+bool cache_args_ok(const float* g_pair, const int32_t* sel, int64_t pair_stride, int n_chains, int64_t n_elem) {
+  return g_pair && sel && pair_stride >= (int64_t)n_chains * n_elem;
+}
+
+}  // namespace
+
+extern "C" int nhmc_leapfrog_first_cached(const float* x_in, float* x_out, float* p, const float* g_pair,
+                                          const int32_t* sel, int64_t pair_stride, const double* eps,
+                                          const double* sigma_y, double m_inv, int n_chains, int64_t n_elem,
+                                          double* sums_ws, nhmc_stream_t stream) {
+  if (!x_in || !x_out || x_in == x_out || !p || !eps || !sigma_y || !sums_ws || n_chains <= 0 || n_elem <= 0 ||
+      !cache_args_ok(g_pair, sel, pair_stride, n_chains, n_elem))
+    return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || (pair_stride & 3) || !nhmc_aligned16(x_in) || !nhmc_aligned16(x_out) || !nhmc_aligned16(p) ||
+      !nhmc_aligned16(g_pair))
+    return NHMC_ERR_ALIGN;
+  LfCache c{sel, (float4*)g_pair, pair_stride / 4, nullptr, nullptr, 0};
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  NHMC_LAUNCH((k_leapfrog<NHMC_LF_FIRST, false, NHMC_VEC_PER_THREAD, true, true>), grid, block, 0, nhmc_s(stream),
+              (const float4*)x_in, (float4*)x_out, (float4*)p, (const float4*)nullptr, (const float4*)nullptr, eps,
+              sigma_y, m_inv, n_elem / 4, sums_ws, c);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_leapfrog_last_cached(float* x, float* p, const float* g, const float* g2, float* g_pair,
+                                         const int32_t* sel, int64_t pair_stride, const double* loss,
+                                         double* loss_pair, int64_t loss_stride, const double* eps,
+                                         const double* sigma_y, double m_inv, int n_chains, int64_t n_elem,
+                                         double* sums_ws, nhmc_stream_t stream) {
+  if (!x || !p || !g || !eps || !sigma_y || !sums_ws || !loss || !loss_pair || loss_stride < n_chains ||
+      n_chains <= 0 || n_elem <= 0 || !cache_args_ok(g_pair, sel, pair_stride, n_chains, n_elem))
+    return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || (pair_stride & 3) || !nhmc_aligned16(x) || !nhmc_aligned16(p) || !nhmc_aligned16(g) ||
+      (g2 && !nhmc_aligned16(g2)) || !nhmc_aligned16(g_pair))
+    return NHMC_ERR_ALIGN;
+  LfCache c{sel, (float4*)g_pair, pair_stride / 4, loss, loss_pair, loss_stride};
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  if (g2)
+    NHMC_LAUNCH((k_leapfrog<NHMC_LF_LAST, true, NHMC_VEC_PER_THREAD, false, true>), grid, block, 0, nhmc_s(stream),
+                (const float4*)nullptr, (float4*)x, (float4*)p, (const float4*)g, (const float4*)g2, eps, sigma_y, m_inv,
+                n_elem / 4, sums_ws, c);
+  else
+    NHMC_LAUNCH((k_leapfrog<NHMC_LF_LAST, false, NHMC_VEC_PER_THREAD, false, true>), grid, block, 0, nhmc_s(stream),
+                (const float4*)nullptr, (float4*)x, (float4*)p, (const float4*)g, (const float4*)nullptr, eps, sigma_y,
+                m_inv, n_elem / 4, sums_ws, c);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_grad_cache_store(const float* g, const float* g2, const double* loss, float* g_pair,
+                                     double* loss_pair, const int32_t* sel, int flip, int64_t pair_stride,
+                                     int64_t loss_stride, int n_chains, int64_t n_elem, nhmc_stream_t stream) {
+  if (!g || !loss || !loss_pair || loss_stride < n_chains || n_chains <= 0 || n_elem <= 0 || (flip & ~1) ||
+      !cache_args_ok(g_pair, sel, pair_stride, n_chains, n_elem))
+    return NHMC_ERR_ARG;
+  if (n_chains > 65535) return NHMC_ERR_SHAPE;
+  if ((n_elem & 3) || (pair_stride & 3) || !nhmc_aligned16(g) || (g2 && !nhmc_aligned16(g2)) || !nhmc_aligned16(g_pair))
+    return NHMC_ERR_ALIGN;
+  LfCache c{sel, (float4*)g_pair, pair_stride / 4, loss, loss_pair, loss_stride};
+  dim3 grid((unsigned)nhmc_leapfrog_tiles(n_elem), (unsigned)n_chains), block(NHMC_BLOCK);
+  NHMC_LAUNCH(k_grad_cache_store, grid, block, 0, nhmc_s(stream), (const float4*)g, (const float4*)g2, c, flip,
+              n_elem / 4);
+  return nhmc_launch_status();
+}
+
+extern "C" int nhmc_grad_cache_flip(const int32_t* accept, int32_t* sel, int n_chains, nhmc_stream_t stream) {
+  if (!accept || !sel || n_chains <= 0) return NHMC_ERR_ARG;
+  NHMC_LAUNCH(k_grad_cache_flip, dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, nhmc_s(stream), accept, sel,
+              n_chains);
   return nhmc_launch_status();
 }
 

@@ -11,7 +11,8 @@ namespace {
 // ---- a5 -------------------------------------------------------------------------------------
 __global__ void k_hamiltonian(const double* __restrict__ sums_ws, int tiles, const double* __restrict__ loss,
                               const double* __restrict__ sigma_y, double m_inv, float* __restrict__ H_out,
-                              double* __restrict__ terms, int n_chains) {
+                              double* __restrict__ terms, int n_chains, const int32_t* __restrict__ sel = nullptr,
+                              int64_t loss_stride = 0) {
   const int chain = blockIdx.x * (blockDim.x / NHMC_WAVE) + (threadIdx.x >> 6);
   if (chain >= n_chains) return;
   const int lane = threadIdx.x & 63;
@@ -25,13 +26,14 @@ __global__ void k_hamiltonian(const double* __restrict__ sums_ws, int tiles, con
   if (lane == 0) {
     const double s = sigma_y[chain];
     const float kf = (float)(1.0 / (2.0 * (s * s)));
-    const float Sx = (float)sx, Sp = (float)sp, L = (float)loss[chain], mi = (float)m_inv;
+    const double lossv = sel ? loss[(int64_t)(sel[chain] & 1) * loss_stride + chain] : loss[chain];
+    const float Sx = (float)sx, Sp = (float)sp, L = (float)lossv, mi = (float)m_inv;
     // (1/2)*sum(x^2) + k*loss + (1/2)*sum(p*p)*m^-1, left to right in fp32 (main_sampling.py:697)
     const float a = 0.5f * Sx;
     const float b = kf * L;
     const float c = (0.5f * Sp) * mi;
     H_out[chain] = (a + b) + c;
-    if (terms) { terms[chain * 3 + 0] = sx; terms[chain * 3 + 1] = sp; terms[chain * 3 + 2] = loss[chain]; }
+    if (terms) { terms[chain * 3 + 0] = sx; terms[chain * 3 + 1] = sp; terms[chain * 3 + 2] = lossv; }
   }
 }
 
@@ -270,7 +272,18 @@ extern "C" int nhmc_hamiltonian(const double* sums_ws, int tiles, const double* 
                                 double m_inv, float* H_out, double* terms, int n_chains, nhmc_stream_t stream) {
   if (!sums_ws || !loss || !sigma_y || !H_out || tiles <= 0 || n_chains <= 0) return NHMC_ERR_ARG;
   NHMC_LAUNCH(k_hamiltonian, wave_grid(n_chains), dim3(256), 0, nhmc_s(stream), sums_ws, tiles, loss, sigma_y,
-                     m_inv, H_out, terms, n_chains);
+                     m_inv, H_out, terms, n_chains, (const int32_t*)nullptr, (int64_t)0);
+  return nhmc_launch_status();
+}
+
+// H at the accepted position with the loss taken from the gradient cache: loss_pair[sel[chain]][chain]
+extern "C" int nhmc_hamiltonian_cached(const double* sums_ws, int tiles, const double* loss_pair, const int32_t* sel,
+                                       int64_t loss_stride, const double* sigma_y, double m_inv, float* H_out,
+                                       double* terms, int n_chains, nhmc_stream_t stream) {
+  if (!sums_ws || !loss_pair || !sel || !sigma_y || !H_out || tiles <= 0 || n_chains <= 0 || loss_stride < n_chains)
+    return NHMC_ERR_ARG;
+  NHMC_LAUNCH(k_hamiltonian, wave_grid(n_chains), dim3(256), 0, nhmc_s(stream), sums_ws, tiles, loss_pair, sigma_y,
+              m_inv, H_out, terms, n_chains, sel, loss_stride);
   return nhmc_launch_status();
 }
 

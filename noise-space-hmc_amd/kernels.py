@@ -89,6 +89,79 @@ def leapfrog_first(x_in, x_out, p, g, eps, sigma_y, m_inv, sums_ws, g2=None):
     _lib.check(rc, 'nhmc_leapfrog_first')
 
 
+# ---- gradient cache (nhmc.h "Gradient cache") -------------------------------------------------
+def _cache_args(g_pair, loss_pair, sel, B, N):
+    """g_pair: a [2, B_total, ...] float32 tensor or a [:, lo:hi] view of one; loss_pair [2, B_total] float64 likewise;
+    sel int32 [B].  -> (pair_stride, loss_stride) in elements."""
+    if g_pair.dim() < 2 or g_pair.shape[0] != 2 or g_pair.shape[1] != B or g_pair[0, 0].numel() != N:
+        raise _lib.NhmcError(f'g_pair must be [2, {B}, ...] with {N} elements per chain, got {tuple(g_pair.shape)}')
+    if not g_pair[0].is_contiguous() or g_pair.dtype != torch.float32 or not g_pair.is_cuda:
+        raise _lib.NhmcError('g_pair: float32 on the GPU, each slot contiguous')
+    if loss_pair.shape != (2, B) or loss_pair.dtype != torch.float64 or loss_pair.stride(1) != 1:
+        raise _lib.NhmcError('loss_pair must be float64 [2, n_chains] (or a [:, lo:hi] view)')
+    if sel.dtype != torch.int32 or sel.numel() != B or not sel.is_contiguous():
+        raise _lib.NhmcError('sel must be int32 [n_chains]')
+    return g_pair.stride(0), loss_pair.stride(0)
+
+
+def grad_cache_store(g, g2, loss, g_pair, loss_pair, sel, flip=0):
+    """slot (sel ^ flip) of every chain <- (g + g2, loss)"""
+    lib = _lib.load()
+    B, N = _chains_elems(g)
+    ps, ls = _cache_args(g_pair, loss_pair, sel, B, N)
+    if g2 is not None and g2.shape != g.shape:
+        raise _lib.NhmcError('g and g2 must have the same shape')
+    rc = lib.nhmc_grad_cache_store(_p(g, torch.float32, 'g'), _p(g2, torch.float32, 'g2'), _p(loss, torch.float64, 'loss'),
+                                   C.c_void_p(g_pair.data_ptr()), C.c_void_p(loss_pair.data_ptr()), _p(sel, torch.int32),
+                                   int(flip), ps, ls, B, N, _stream())
+    _lib.check(rc, 'nhmc_grad_cache_store')
+
+
+def leapfrog_first_cached(x_in, x_out, p, g_pair, sel, eps, sigma_y, m_inv, sums_ws):
+    """FIRST half step (out of place in x) with the gradient read from the cache slot sel[chain]."""
+    lib = _lib.load()
+    B, N = _chains_elems(x_in)
+    if x_out.shape != x_in.shape or p.shape != x_in.shape:
+        raise _lib.NhmcError('x_in, x_out, p must have the same shape')
+    if g_pair.dim() < 2 or g_pair.shape[0] != 2 or g_pair.shape[1] != B or g_pair[0, 0].numel() != N or \
+            not g_pair[0].is_contiguous() or sel.numel() != B:
+        raise _lib.NhmcError('g_pair must be [2, n_chains, ...] like x, sel int32 [n_chains]')
+    eps, sigma_y = _f64(eps, B, x_in.device), _f64(sigma_y, B, x_in.device)
+    if sums_ws is None or sums_ws.numel() < B * leapfrog_tiles(N) * 2:
+        raise _lib.NhmcError('sums_ws missing or too small')
+    rc = lib.nhmc_leapfrog_first_cached(_p(x_in, torch.float32, 'x_in'), _p(x_out, torch.float32, 'x_out'),
+                                        _p(p, torch.float32, 'p'), C.c_void_p(g_pair.data_ptr()), _p(sel, torch.int32, 'sel'),
+                                        g_pair.stride(0), _p(eps, torch.float64), _p(sigma_y, torch.float64), float(m_inv),
+                                        B, N, _p(sums_ws, torch.float64), _stream())
+    _lib.check(rc, 'nhmc_leapfrog_first_cached')
+
+
+def leapfrog_last_cached(x, p, g, g2, g_pair, loss_pair, sel, loss, eps, sigma_y, m_inv, sums_ws):
+    """LAST step; slot 1 - sel[chain] <- (g + g2, loss) of the trajectory's end point."""
+    lib = _lib.load()
+    B, N = _chains_elems(x)
+    if p.shape != x.shape or g.shape != x.shape or (g2 is not None and g2.shape != x.shape):
+        raise _lib.NhmcError('x, p, g (and g2) must have the same shape')
+    ps, ls = _cache_args(g_pair, loss_pair, sel, B, N)
+    eps, sigma_y = _f64(eps, B, x.device), _f64(sigma_y, B, x.device)
+    if sums_ws is None or sums_ws.numel() < B * leapfrog_tiles(N) * 2:
+        raise _lib.NhmcError('sums_ws missing or too small')
+    if loss.numel() != B:
+        raise _lib.NhmcError('loss must have one entry per chain')
+    rc = lib.nhmc_leapfrog_last_cached(_p(x, torch.float32, 'x'), _p(p, torch.float32, 'p'), _p(g, torch.float32, 'g'),
+                                       _p(g2, torch.float32, 'g2'), C.c_void_p(g_pair.data_ptr()), _p(sel, torch.int32),
+                                       ps, _p(loss, torch.float64, 'loss'), C.c_void_p(loss_pair.data_ptr()), ls,
+                                       _p(eps, torch.float64), _p(sigma_y, torch.float64), float(m_inv), B, N,
+                                       _p(sums_ws, torch.float64), _stream())
+    _lib.check(rc, 'nhmc_leapfrog_last_cached')
+
+
+def grad_cache_flip(accept, sel):
+    lib = _lib.load()
+    _lib.check(lib.nhmc_grad_cache_flip(_p(accept, torch.int32, 'accept'), _p(sel, torch.int32, 'sel'), sel.numel(), _stream()),
+               'nhmc_grad_cache_flip')
+
+
 # ---- a9-a11 ---------------------------------------------------------------------------------
 def _mix_shapes(xt, e):
     B, Cc = xt.shape[0], xt.shape[1]
@@ -499,8 +572,21 @@ def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=Non
 
 
 # ---- a5-a7 ----------------------------------------------------------------------------------
-def hamiltonian(sums_ws, n_elem, loss, sigma_y, m_inv, want_terms=False):
+def hamiltonian(sums_ws, n_elem, loss, sigma_y, m_inv, want_terms=False, sel=None):
+    """sel (int32 [B]): loss is then the gradient cache's loss_pair [2, B] and chain c uses loss[sel[c], c]."""
     lib = _lib.load()
+    if sel is not None:
+        B = sel.numel()
+        if loss.shape != (2, B) or loss.dtype != torch.float64 or loss.stride(1) != 1:
+            raise _lib.NhmcError('hamiltonian(sel=...): loss must be the float64 [2, n_chains] cache')
+        H = torch.empty(B, dtype=torch.float32, device=loss.device)
+        terms = torch.empty(B, 3, dtype=torch.float64, device=loss.device) if want_terms else None
+        sy = _f64(sigma_y, B, loss.device)
+        rc = lib.nhmc_hamiltonian_cached(_p(sums_ws, torch.float64), leapfrog_tiles(n_elem), C.c_void_p(loss.data_ptr()),
+                                         _p(sel, torch.int32, 'sel'), loss.stride(0), _p(sy), float(m_inv), _p(H), _p(terms),
+                                         B, _stream())
+        _lib.check(rc, 'nhmc_hamiltonian_cached')
+        return (H, terms) if want_terms else H
     B = loss.numel()
     H = torch.empty(B, dtype=torch.float32, device=loss.device)
     terms = torch.empty(B, 3, dtype=torch.float64, device=loss.device) if want_terms else None

@@ -105,6 +105,8 @@ class LeapfrogEngine:
         self._ge = {}                          # score-output shape -> persistent g_e buffers (sigma-channels stay zero)
         self._outs = None                      # batch-wide decode / loss buffers of `step`
         self.update_events = None              # bench: list collecting (start, end, chains) event pairs of each update launch
+        self.n_ladders = 0                     # decode + gradient ladders launched (one per chunk) ...
+        self.n_chain_ladders = 0               # ... and the chains they carried (score evaluations = n_steps x this)
         steps = list(zip(reversed(seq), reversed(seq_next)))
         from .schedule import alpha_bar_table
         table = alpha_table.to(device).float() if alpha_table is not None else alpha_bar_table(b)
@@ -161,11 +163,22 @@ class LeapfrogEngine:
                 gb[lo:hi].copy_(b_)
         return xt_out, loss, ga, gb
 
-    def step(self, mode, x_in, x, p, y, eps, sigma_y, m_inv, ws, graph=False):
+    def prime(self, cache, x, y, graph=False):
+        """Decode + gradient at x into the cache slot `sel` of every chain: the once-per-run evaluation at the start
+        point (every later trajectory finds its first gradient in the cache)."""
+        xt_out, loss = self._out_buffers(x)
+        run = self._graphed_chunk if graph else self._decode_and_grad_chunk
+        for lo, hi in self._chunks(x.shape[0]):
+            ga, gb = run(x[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi])
+            K.grad_cache_store(ga, gb, loss[lo:hi], cache.g[:, lo:hi], cache.loss[:, lo:hi], cache.sel[lo:hi])
+        cache.valid = True
+
+    def step(self, mode, x_in, x, p, y, eps, sigma_y, m_inv, ws, graph=False, cache=None):
         """Decode + gradient at x_in, then the fused leapfrog update of (x, p), chunk by chunk: every kernel writes
         its slice of the batch-wide outputs and each chunk's two gradient pieces go straight into the update --
         no gather copies, no clone of the position.  mode FIRST: out of place (x_in -> x, x_in kept); MID / LAST:
-        x_in is x.  -> (xt, loss): batch-wide buffers owned by the engine, valid until the next step."""
+        x_in is x.  cache (a GradCache, LAST only): the end point's loss and summed gradient are also stored in the
+        chains' free cache slots.  -> (xt, loss): batch-wide buffers owned by the engine, valid until the next step."""
         B, N = x.shape[0], x[0].numel()
         xt_out, loss = self._out_buffers(x)
         tiles2 = 2 * K.leapfrog_tiles(N)
@@ -178,6 +191,9 @@ class LeapfrogEngine:
                 ev[0].record()
             if mode == K.LF_FIRST:
                 K.leapfrog_first(x_in[lo:hi], x[lo:hi], p[lo:hi], ga, eps[lo:hi], sigma_y[lo:hi], m_inv, w, g2=gb)
+            elif mode == K.LF_LAST and cache is not None:
+                K.leapfrog_last_cached(x[lo:hi], p[lo:hi], ga, gb, cache.g[:, lo:hi], cache.loss[:, lo:hi],
+                                       cache.sel[lo:hi], loss[lo:hi], eps[lo:hi], sigma_y[lo:hi], m_inv, w)
             else:
                 K.leapfrog_fused(mode, x[lo:hi], p[lo:hi], ga, eps[lo:hi], sigma_y[lo:hi], m_inv, w, g2=gb)
             if self.update_events is not None:
@@ -214,6 +230,8 @@ class LeapfrogEngine:
         batch-wide buffers) and returns the chunk's gradient pieces (g_direct, g_score or None)."""
         n = x.shape[0]
         S = self.n_steps
+        self.n_ladders += 1
+        self.n_chain_ladders += n
         tab = self._tables(n)
         ins, outs = [], []
         cur = x
@@ -301,32 +319,92 @@ class ChainState:
     def get(self, k, default=None):
         return self.t.get(k, default)
 
+    def view(self, n):
+        """The first n chains' state (same storage): what the kernels see after compaction."""
+        v = object.__new__(ChainState)
+        v.t = {k: a[:n] for k, a in self.t.items()}
+        return v
 
-def run_trajectory(engine, x, p, y, state, m, L, ws=None, graph=False, x_prop=None):
+    def permute(self, order):
+        self.t = {k: a.index_select(0, order) for k, a in self.t.items()}
+
+
+class GradCache:
+    """Loss and summed gradient at every chain's accepted position, and room for the next proposal's: two slots per
+    chain, `sel[c]` = the slot that belongs to chain c's accepted position (include/nhmc.h, "Gradient cache").
+
+    The reference evaluates decode + loss + gradient at x at the top of every outer iteration (main_sampling.py:693-695)
+    -- a point it already evaluated: in the previous iteration's last leapfrog step if that proposal was accepted
+    (:709-711 at x_proposal, then x = x_proposal :731), in the previous iteration's own :693-695 if it was rejected.
+    Neither loss nor gradient depends on sigma_y / eps (they enter in the update and in H), so the values are
+    bit-identical; with the cache a trajectory costs L score ladders instead of L + 1."""
+
+    def __init__(self, x):
+        B = x.shape[0]
+        self.g = torch.empty((2,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        self.loss = torch.zeros(2, B, dtype=torch.float64, device=x.device)
+        self.sel = torch.zeros(B, dtype=torch.int32, device=x.device)
+        self.valid = False
+
+    def view(self, n):
+        """The first n chains' share (the active prefix after compaction): same storage."""
+        v = object.__new__(GradCache)
+        v.g, v.loss, v.sel, v.valid = self.g[:, :n], self.loss[:, :n], self.sel[:n], self.valid
+        return v
+
+    def permute(self, order):
+        self.g = self.g.index_select(1, order)
+        self.loss = self.loss.index_select(1, order)
+        self.sel = self.sel.index_select(0, order)
+
+
+def run_trajectory(engine, x, p, y, state, m, L, ws=None, graph=False, x_prop=None, cache=None):
     """One outer iteration (main_sampling.py:693-718) for all chains.  x is NOT modified; p is updated in place.
     x_prop: optional buffer for the proposal (kept by the caller across trajectories; allocated here otherwise).
+    cache: a GradCache kept by the caller across trajectories.  With it the first half step takes loss and gradient
+    at x from the cache (primed here on first use) instead of decoding x again, and the last step leaves the end
+    point's in the chains' free slots; the CALLER flips `cache.sel` for accepted chains (K.grad_cache_flip).
     -> dict(x_prop, p, xt, loss, H0, H1); xt / loss are the engine's buffers, valid until its next step."""
     B, N = x.shape[0], x[0].numel()
     m_inv = m ** (-1)
     eps, sig = state['eps_eff'], state['sigma_y']
     ws = ws if ws is not None else K.leapfrog_ws(B, N, x.device)
     x_prop = x_prop if x_prop is not None else torch.empty_like(x)
-    xt, loss = engine.step(K.LF_FIRST, x, x_prop, p, y, eps, sig, m_inv, ws, graph=graph)
-    H0 = K.hamiltonian(ws, N, loss, sig, m_inv)
+    if cache is None:
+        xt, loss = engine.step(K.LF_FIRST, x, x_prop, p, y, eps, sig, m_inv, ws, graph=graph)
+        H0 = K.hamiltonian(ws, N, loss, sig, m_inv)
+    else:
+        if not cache.valid:
+            engine.prime(cache, x, y, graph=graph)
+        K.leapfrog_first_cached(x, x_prop, p, cache.g, cache.sel, eps, sig, m_inv, ws)
+        H0 = K.hamiltonian(ws, N, cache.loss, sig, m_inv, sel=cache.sel)
     for l in range(L):
-        xt, loss = engine.step(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, x_prop, p, y, eps, sig, m_inv, ws, graph=graph)
+        xt, loss = engine.step(K.LF_MID if l < L - 1 else K.LF_LAST, x_prop, x_prop, p, y, eps, sig, m_inv, ws,
+                               graph=graph, cache=cache)
     H1 = K.hamiltonian(ws, N, loss, sig, m_inv)
     return dict(x_prop=x_prop, p=p, xt=xt, loss=loss, H0=H0, H1=H1)
 
 
 def hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, epochs=60, sampling=20,
-               chunk=None, max_iters=None, log=None, collect_trace=False, graph=False):
-    """Per-chain HMC for B = x.shape[0] chains (graph=True: hipGraph replay of each decode+gradient chunk).  Returns a SimpleNamespace:
+               chunk=None, max_iters=None, log=None, collect_trace=False, graph=False, reuse=True, compact=True,
+               compact_quantum=None):
+    """Per-chain HMC for B = x.shape[0] chains (graph=True: hipGraph replay of each decode+gradient chunk).
+
+    reuse    the first half step of a trajectory takes loss and gradient at x from the GradCache instead of decoding
+             x again: L score ladders per trajectory (+ one per run) instead of L + 1, same bits.
+    compact  chains that reached their last epoch leave the batch: the per-chain state is kept partitioned (running
+             chains first, in their original order) and every kernel and score call runs on the running prefix,
+             rounded up to a multiple of `compact_quantum` chains (default: the score chunk, else B // 8) so that the
+             score network sees few distinct batch sizes.  Noise is still drawn for all B chains in chain order, so a
+             chain's run does not depend on when the others finish.
+    Returns a SimpleNamespace (per-chain results in the caller's chain order):
         samples [B, sampling, C, H, W]   accepted decodes of epochs epochs+sampling .. epochs+2*sampling-1
         x       [B, C, H, W]             final noise-space positions
         n_accept, n_reject, epoch [B]    int32
         psnr    [B] or None              PSNR of the last accepted decode against x_orig
         iters   int                      trajectories run
+        ladders, chain_ladders           decode+gradient ladders launched / chains they carried (score calls = 3 x)
+        chain_trajectories               sum over trajectories of the chains that ran it
         trace   list of dicts (dH, accept, epoch per iteration) when collect_trace
     """
     device = x.device
@@ -344,36 +422,86 @@ def hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noi
     engine = LeapfrogEngine(score, operator, b, seq, seq_next, device, chunk=chunk)
     x = x.detach().clone().contiguous()
     y_0 = y_0.contiguous()
+    x_orig = x_orig.contiguous() if x_orig is not None else None
     state = ChainState(B, tau, epsilon, device)
     samples = torch.zeros((B, sampling) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
     xt_last = torch.zeros_like(x)
     ws = K.leapfrog_ws(B, N, device)
     x_prop = torch.empty_like(x)
+    cache = GradCache(x) if reuse else None
+    if cache is not None:
+        engine.prime(cache, x, y_0, graph=graph)
+    quantum = int(compact_quantum or (chunk if chunk and chunk < B else max(1, B // 8)))
+    ids, ids_dev, n_run = list(range(B)), None, B       # slot -> chain id; chains [0, n_run) of the slot order run
+    chain_trajectories = 0
     trace = [] if collect_trace else None
     it = 0
+
+    def in_chain_order(v, fill=0):
+        """[n_run] or [B] slot-ordered device vector -> [B] host vector in the caller's chain order."""
+        v = v.detach().cpu()
+        if v.numel() < B:
+            v = torch.cat([v, torch.full((B - v.numel(),), fill, dtype=v.dtype)])
+        if ids_dev is None:
+            return v.clone()
+        out = torch.empty_like(v)
+        out[torch.tensor(ids)] = v
+        return out
+
     while True:
-        K.schedule_begin(state, sigma_0, epochs, sampling)
-        p = noise.momentum(it, x, math.sqrt(m))
-        out = run_trajectory(engine, x, p, y_0, state, m, L, ws, graph=graph, x_prop=x_prop)
+        sv = state if n_run == B else state.view(n_run)
+        K.schedule_begin(sv, sigma_0, epochs, sampling)
+        p = noise.momentum(it, x, math.sqrt(m))                            # all B chains, chain order
         u = noise.uniform(it, B, device)
-        accept, dH = K.metropolis(out['H0'], out['H1'], u, state['active'])
-        K.accept_commit(accept, state['epoch'], x, out['x_prop'], out['xt'], samples, epochs, sampling)
-        K.accept_commit(accept, state['epoch'], xt_last, out['xt'], None, None, epochs, sampling)
-        epoch_before = state['epoch'].clone() if (collect_trace or log) else None
-        K.schedule_end(accept, state)
+        if ids_dev is not None:
+            p, u = p.index_select(0, ids_dev[:n_run]), u.index_select(0, ids_dev[:n_run])
+        out = run_trajectory(engine, x[:n_run], p, y_0[:n_run], sv, m, L, ws, graph=graph, x_prop=x_prop[:n_run],
+                             cache=cache.view(n_run) if cache is not None else None)
+        accept, dH = K.metropolis(out['H0'], out['H1'], u, sv['active'])
+        K.accept_commit(accept, sv['epoch'], x[:n_run], out['x_prop'], out['xt'], samples[:n_run], epochs, sampling)
+        K.accept_commit(accept, sv['epoch'], xt_last[:n_run], out['xt'], None, None, epochs, sampling)
+        if cache is not None:
+            K.grad_cache_flip(accept, cache.sel[:n_run])
+        epoch_before = sv['epoch'].clone() if (collect_trace or log) else None
+        K.schedule_end(accept, sv)
         it += 1
-        # the one host read per trajectory: termination (and optional logging)
-        status = torch.stack([state['epoch'], accept]).cpu()
+        chain_trajectories += n_run
+        # the one host read per trajectory: termination, compaction (and optional logging)
+        status = torch.stack([sv['epoch'], accept]).cpu()
         if collect_trace:
-            trace.append(dict(dH=dH.cpu(), accept=status[1].clone(), epoch=epoch_before.cpu(),
-                              sigma_y=state['sigma_y'].cpu().clone(), eps=state['eps'].cpu().clone()))
+            trace.append(dict(dH=in_chain_order(dH), accept=in_chain_order(accept), epoch=in_chain_order(epoch_before, total),
+                              sigma_y=in_chain_order(state['sigma_y']), eps=in_chain_order(state['eps'])))
         if log is not None:
-            log(it, status, state, out, x_orig)
-        if int(status[0].min()) >= total or (max_iters is not None and it >= max_iters):
+            log(it, status, sv, out, x_orig[:n_run] if x_orig is not None else None, ids[:n_run])
+        ep = status[0].tolist()
+        n_act = sum(1 for e in ep if e < total)
+        if n_act == 0 or (max_iters is not None and it >= max_iters):
             break
-    psnr = K.psnr(xt_last, x_orig.contiguous()) if x_orig is not None else None
+        want = min(n_run, -(-n_act // quantum) * quantum)
+        if compact and want < n_run:
+            order = [s_ for s_ in range(n_run) if ep[s_] < total] + [s_ for s_ in range(n_run) if ep[s_] >= total] + \
+                list(range(n_run, B))
+            od = torch.tensor(order, device=device)
+            x, y_0, samples, xt_last = (t.index_select(0, od) for t in (x, y_0, samples, xt_last))
+            x_orig = x_orig.index_select(0, od) if x_orig is not None else None
+            state.permute(od)
+            if cache is not None:
+                cache.permute(od)
+            ids = [ids[s_] for s_ in order]
+            ids_dev = torch.tensor(ids, device=device)
+            n_run = want
+    if ids_dev is not None:                                                 # back to the caller's chain order
+        inv = torch.empty(B, dtype=torch.int64)
+        inv[torch.tensor(ids)] = torch.arange(B)
+        inv = inv.to(device)
+        x, samples, xt_last = (t.index_select(0, inv) for t in (x, samples, xt_last))
+        x_orig = x_orig.index_select(0, inv) if x_orig is not None else None
+        state.permute(inv)
+    psnr = K.psnr(xt_last, x_orig) if x_orig is not None else None
     return SimpleNamespace(samples=samples, x=x, n_accept=state['n_accept'], n_reject=state['n_reject'],
-                           epoch=state['epoch'], psnr=psnr, iters=it, trace=trace, xt=xt_last, L=L)
+                           epoch=state['epoch'], psnr=psnr, iters=it, trace=trace, xt=xt_last, L=L,
+                           ladders=engine.n_ladders, chain_ladders=engine.n_chain_ladders,
+                           chain_trajectories=chain_trajectories)
 
 
 def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
@@ -390,27 +518,32 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
         seed = getattr(opt, 'philox_seed', None)
         noise = PhiloxNoise(seed, getattr(opt, 'chain_id0', 0)) if seed is not None else TorchNoise()
 
-    def log(it, status, state, out, x_orig_):
-        if quiet or not bool(status[1][0]):
+    def log(it, status, state, out, x_orig_, ids):
+        if quiet or 0 not in ids:
             return
-        ps = K.psnr(out['xt'][:1].contiguous(), x_orig_[:1].contiguous())
-        print('epoch', int(status[0][0]), 'PSNR:', float(ps[0]), 'sigma_y:', float(state['sigma_y'][0]),
-              'tau:', float(state['tau'][0]))
+        s0 = ids.index(0)                                  # chain 0's slot (compaction may have moved it)
+        if not bool(status[1][s0]):
+            return
+        ps = K.psnr(out['xt'][s0:s0 + 1].contiguous(), x_orig_[s0:s0 + 1].contiguous())
+        print('epoch', int(status[0][s0]), 'PSNR:', float(ps[0]), 'sigma_y:', float(state['sigma_y'][s0]),
+              'tau:', float(state['tau'][s0]))
         if getattr(opt, 'save_images', False):
-            _save_png(out['xt'][0], os.path.join(opt.image_folder, f'hmc_{int(status[0][0])}.png'))
+            _save_png(out['xt'][s0], os.path.join(opt.image_folder, f'hmc_{int(status[0][s0])}.png'))
 
     every = int(getattr(opt, 'progress_every', 0) or 0)
 
-    def progress(it, status, state, out, x_orig_):
+    def progress(it, status, state, out, x_orig_, ids):
         if every and it % every == 0:
             import sys
-            print(f'[hmc] trajectory {it}: epochs min {int(status[0].min())} max {int(status[0].max())}, '
-                  f'accepted this round {int(status[1].sum())}/{status.shape[1]}', file=sys.stderr, flush=True)
+            print(f'[hmc] trajectory {it}: {status.shape[1]} chains in the batch, epochs min {int(status[0].min())} '
+                  f'max {int(status[0].max())}, accepted this round {int(status[1].sum())}/{status.shape[1]}',
+                  file=sys.stderr, flush=True)
 
     res = hmc_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig, noise=noise,
                      epochs=int(getattr(opt, 'hmc_epochs', 60)), sampling=int(getattr(opt, 'hmc_sampling', 20)),
                      chunk=getattr(opt, 'score_chunk', None), log=(progress if every else None) if quiet else log,
-                     graph=bool(getattr(opt, 'use_graph', False)))
+                     graph=bool(getattr(opt, 'use_graph', False)), reuse=bool(getattr(opt, 'reuse_gradient', True)),
+                     compact=bool(getattr(opt, 'compact_chains', True)))
     return res.samples[0] if n == 1 else res.samples
 
 
@@ -493,7 +626,7 @@ def hmc_test_conditioning(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_ori
 # latent variant
 # --------------------------------------------------------------------------------------------- #
 def hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, epochs=50, sampling=10,
-                      chunk=None, collect_trace=False):
+                      chunk=None, collect_trace=False, reuse=True):
     """Per-chain form of `hmc_latent` (main_sampling_latent.py:623-762).  The epoch index is the shared loop
     counter (a reject consumes its epoch, :646,733); sigma_y / tau / eps / reject counter / sample ring are per
     chain.  Returns SimpleNamespace(samples [B, <=sampling latents...] as a list per chain, x, n_accept, trace)."""
@@ -519,13 +652,16 @@ def hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *,
     xt_last = torch.zeros_like(x)
     ws = K.leapfrog_ws(B, N, device)
     x_prop = torch.empty_like(x)
+    cache = GradCache(x) if reuse else None          # :650-652 re-evaluates a point the previous iteration already has
     trace = [] if collect_trace else None
     for epoch in range(epochs + 2 * sampling):
         st['eps_eff'].copy_(st['eps'])
         p = noise.momentum(epoch, x, math.sqrt(m))
-        out = run_trajectory(engine, x, p, y_0, st, m, L, ws, x_prop=x_prop)
+        out = run_trajectory(engine, x, p, y_0, st, m, L, ws, x_prop=x_prop, cache=cache)
         u = noise.uniform(epoch, B, device)
         accept, dH = K.metropolis(out['H0'], out['H1'], u, None)
+        if cache is not None:
+            K.grad_cache_flip(accept, cache.sel)
         final = epoch >= epochs
         sig_next = sigma_0 if final else sigma_y0 * (sigma_0 / sigma_y0) ** (epoch / epochs)   # :693-695,705-706
         if collect_trace:
@@ -538,7 +674,8 @@ def hmc_latent_chains(x, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *,
         k = min(count[c], sampling)
         order = [(count[c] - k + j) % sampling for j in range(k)]
         samples.append(ring[c, order])
-    return SimpleNamespace(samples=samples, x=x, n_accept=st['n_accept'], count=count, trace=trace, xt=xt_last, L=L)
+    return SimpleNamespace(samples=samples, x=x, n_accept=st['n_accept'], count=count, trace=trace, xt=xt_last, L=L,
+                           ladders=engine.n_ladders, chain_ladders=engine.n_chain_ladders)
 
 
 def hmc_latent(x, n, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.nhmc_abi_version() == 1
+    assert lib.nhmc_abi_version() == 2
     assert lib.nhmc_status_string(0) == b'ok' and b'aligned' in lib.nhmc_status_string(2)
     n = 3 * 256 * 256
     assert lib.nhmc_leapfrog_tiles(n) == 96 and lib.nhmc_leapfrog_tiles(3 * 16 * 16) == 1
