@@ -65,6 +65,11 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='chains per GPU (BASELINE: 64; 16 with --latent)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-by-deg', action='store_true', help='skip the sr4 / deblur_aniso legs')
+    ap.add_argument('--no-full-run', action='store_true', help='skip the whole-trajectory leg (sampler.hmc_chains itself)')
+    ap.add_argument('--full-run-tau', type=float, default=0.25,
+                    help='tau of the whole-trajectory leg (L = floor(tau / 0.05) leapfrog steps per trajectory; the reference '
+                         'default 1.0 gives L = 20 = 33 s per trajectory at 64 chains)')
+    ap.add_argument('--full-run-trajectories', type=int, default=4)
     ap.add_argument('--kernel-only', action='store_true', help='skip the end-to-end steps (profiling the HIP kernels)')
     ap.add_argument('--roofline-launches', type=int, default=200)
     ap.add_argument('--deg', default='inpaint_random',
@@ -424,6 +429,36 @@ def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding
     return dt, loss.clone(), events
 
 
+def full_run_leg(device, prob, B, chunk, tau, trajectories):
+    """The sampler as a user runs it: `sampler.hmc_chains` for a few COMPLETE trajectories of all B chains -- the
+    once-per-run evaluation at the start point, per trajectory the schedule kernel, the momentum draw, the first half
+    step from the gradient cache, L x (score ladder + data term + backward + fused update), both Hamiltonians, the
+    Metropolis test, the accept commits, the cache flip and the one status read.  tau is shortened (L = floor(tau / eps))
+    so the leg fits the bench's time budget; per score ladder the cost must equal the headline step's."""
+    import types
+    from nhmc import sampler
+    opt = types.SimpleNamespace(tau=tau, epsilon=EPS, m=1.0, sigma_0=2 * prob['sigma0'])
+    x_orig = prob['x'].clamp(-1, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = sampler.hmc_chains(prob['x'], prob['b'], prob['seq'], prob['seq_next'], prob['algo'], opt, prob['y'], prob['op'], x_orig,
+                             noise=sampler.PhiloxNoise(5678, 0), chunk=chunk, max_iters=trajectories)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L, iters = res.L, res.iters
+    chunks = 1 if not chunk or chunk >= B else -(-B // chunk)
+    batch_ladders = res.ladders / chunks                               # batch-wide score ladders: iters * L + 1 (the start point)
+    return dict(value=round(B * iters * L / dt, 3), unit='chain-steps/s', trajectories=iters, leapfrog_steps_per_trajectory=L,
+                tau=tau, chains=B, seconds=round(dt, 2), score_ladders=batch_ladders,
+                score_ladders_per_trajectory=round((batch_ladders - 1) / iters, 3),
+                score_ladders_without_the_gradient_cache=iters * (L + 1),
+                ms_per_ladder=round(1e3 * dt / batch_ladders, 2),
+                accepted=int(res.n_accept.sum()), rejected=int(res.n_reject.sum()),
+                note='sampler.hmc_chains end to end (prime + trajectories, every kernel and the per-trajectory status read inside '
+                     'the timed region); value = chains x trajectories x L / seconds; ms_per_ladder (per batch-wide score ladder, '
+                     'the once-per-run start-point evaluation included) is comparable with ms_per_step')
+
+
 def degradation_leg(device, deg, model, B, chunk, steps=2):
     """configs[2] / configs[3]: the same step with another operator -- hot path, data-term roofline, a few end-to-end steps."""
     import nhmc.kernels as K
@@ -552,8 +587,24 @@ def latent_main(args):
         torch.distributed.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` on its own: start the N ranks as a CHILD torch.distributed.run (one process per GPU)
+    with the same arguments and hand back its exit code.  Called before anything in this process touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] --gpus %d without WORLD_SIZE: launching %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a GPU; the HIP path has no CPU fallback'
     if args.latent:
         return latent_main(args)
@@ -604,7 +655,7 @@ def main():
         torch.cuda.synchronize()
         gather = dict(chains=int(allstats.shape[0]), ms=round(1e3 * (time.perf_counter() - t0), 3),
                       loss_mean=float(allstats[:, 0].double().mean()))
-    roof = hot = cpu = single = by_deg = None
+    roof = hot = cpu = single = by_deg = full = None
     if rank == 0:
         roof = leapfrog_roofline(device, B, args.roofline_launches)
         hot = hot_path_only(device, prob, B, 20, chunk=args.chunk)
@@ -631,6 +682,10 @@ def main():
             by_deg = {}
             for deg in ('sr4', 'deblur_aniso'):
                 by_deg[deg] = degradation_leg(device, deg, prob['model'], B, args.chunk)
+        if world == 1 and not args.kernel_only and not args.no_full_run:
+            full = full_run_leg(device, prob, B, args.chunk, args.full_run_tau, args.full_run_trajectories)
+            if ms_per_step:
+                full['ms_per_ladder_over_ms_per_step'] = round(full['ms_per_ladder'] / ms_per_step, 4)
         if not args.kernel_only:
             single = single_chain_rate(eng, x, p, y, eps, sig, with_graph=(world == 1))
         if by_deg is not None and not args.tiny_score:
@@ -652,7 +707,7 @@ def main():
                                    (' -- REHEARSAL: the ranks share ONE GPU over gloo (not a multi-GPU measurement)' if args.rehearse_shared_gpu else ''),
                        'chains_per_gpu': B, 'global_chains': world * B, 'score_chunk': args.chunk,
                        'parallelism': f'chains sharded over {world} rank(s), no data-path collective'},
-            'roofline': roofline, 'hot_path_only': hot, 'hot_path_kernels': ktable, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
+            'roofline': roofline, 'hot_path_only': hot, 'hot_path_kernels': ktable, 'full_run': full, 'by_deg': by_deg, 'single_chain': single, 'final_gather': gather,
             'peak_memory_gib': round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1), 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

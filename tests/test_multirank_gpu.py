@@ -76,3 +76,31 @@ def test_bench_ranks_halve_the_score_chunk_together(tmp_path):
     assert 'every rank retries with --chunk 2' in out.stderr
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['config']['score_chunk'] == 2 and line['final_gather']['chains'] == 8 and line['value'] > 0
+
+
+def _bare_bench(args, extra_env=None):
+    """`python bench.py --gpus N ...` with NO launcher around it: bench.py must start its own ranks (as a child process)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(extra_env or {}))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=900)
+
+
+@pytest.mark.parametrize('n', [2, 4])        # 4 ranks + this process = 5 processes on the card (the box allows 6)
+def test_bare_bench_command_starts_its_own_ranks(n):
+    out = _bare_bench(['--gpus', str(n), '--steps', '1', '--warmup', '1', '--batch', '2', '--chunk', '2', '--tiny-score',
+                       '--rehearse-shared-gpu', '--no-cpu-baseline', '--roofline-launches', '8'])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f'--gpus {n} without WORLD_SIZE: launching' in out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                               # rank 0 prints the one JSON line
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == n and line['config']['global_chains'] == 2 * n and line['final_gather']['chains'] == 2 * n
+    assert line['value'] > 0 and line['scaling'] == 'weak'
+
+
+def test_bare_bench_command_hands_back_the_ranks_exit_code():
+    out = _bare_bench(['--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '2', '--chunk', '1', '--tiny-score',
+                       '--rehearse-shared-gpu', '--no-cpu-baseline', '--roofline-launches', '8', '--deg', 'no_such_degradation'])
+    assert out.returncode != 0

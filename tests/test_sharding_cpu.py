@@ -67,7 +67,7 @@ def _worker(rank, world, port, n_chains, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_chains', [(2, 6), (2, 5), (3, 4)])
+@pytest.mark.parametrize('world,n_chains', [(2, 6), (2, 5), (3, 4), (8, 512), (8, 13)])       # 8 ranks: the node's width (configs[2])
 def test_gather_chains_over_gloo(tmp_path, world, n_chains):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_chains, str(tmp_path)), nprocs=world, join=True)
