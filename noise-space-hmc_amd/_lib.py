@@ -31,6 +31,7 @@ SIGNATURES = {
     'nhmc_ddim_mix_bwd_inpaint': (I, [P, P, I, P, P, P, P, I64, P, P, I, P, I, I, I64, P]),
     'nhmc_inpaint_px_tiles': (I, [I, I64]),
     'nhmc_ddim_mix_bwd_inpaint_px': (I, [P, P, I, P, P, P, P, P, I64, P, P, I, P, I, I, I64, P]),
+    'nhmc_sr_vjp_tiles': (I, [I, I, I]),
     'nhmc_ddim_mix_bwd_sr': (I, [P, P, I, P, P, P, I, P, P, P, I, I, I, P]),
     'nhmc_data_tiles': (I, [I64]),
     'nhmc_sr_tiles': (I, [I, I, I]),
@@ -59,10 +60,10 @@ SIGNATURES = {
     'nhmc_spectral_project': (I, [P, P, P, P, P, I, I, I, P]),
     'nhmc_data_spectral_proj': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
     'nhmc_data_spectral_proj_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
-    'nhmc_sandwich_rect': (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    'nhmc_sandwich_rect': (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     'nhmc_srconv_tiles': (I, [I, I]),
-    'nhmc_data_srconv': (I, [P, P, P, P, I, P, P, P, I, I, I, I, P]),
-    'nhmc_data_srconv_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P]),
+    'nhmc_data_srconv': (I, [P, P, P, P, P, P, P, I, P, P, P, I, I, I, I, P]),
+    'nhmc_data_srconv_vjp': (I, [P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P]),
     'nhmc_hamiltonian': (I, [P, I, P, P, D, P, P, I, P]),
     'nhmc_metropolis': (I, [P, P, P, P, P, P, I, P]),
     'nhmc_schedule_begin': (I, [P, P, P, P, P, P, D, I, I, I, P]),
@@ -72,7 +73,7 @@ SIGNATURES = {
     'nhmc_schedule_end_latent': (I, [P, P, P, P, P, P, P, P, D, I, I, P]),
     'nhmc_leapfrog_mass': (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I64, P, P]),
     'nhmc_mass_sort_ws_bytes': (SZ, [I, I64]),
-    'nhmc_mass_from_variance': (I, [P, I, P, P, P, P, SZ, I, I64, P]),
+    'nhmc_mass_from_variance': (I, [P, I, P, P, P, P, P, P, SZ, I, I64, P]),
     'nhmc_schedule_begin_mass': (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     'nhmc_vq_nearest': (I, [P, P, P, P, I, I, I64, I, P]),
     'nhmc_gn_splits': (I, [I, I, I, I64]),

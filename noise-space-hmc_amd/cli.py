@@ -19,6 +19,7 @@ term (operators.Deblurring2D).
 import argparse
 import glob
 import os
+import sys
 import random
 
 import numpy as np
@@ -110,17 +111,42 @@ def load_images(folder, size, start, end, synthetic, seed):
     return torch.nn.functional.interpolate(low, size=size, mode='bicubic', align_corners=False).clamp(0, 1) * 2 - 1
 
 
-def auto_score_chunk(opt, config, device):
-    """Chains per score call when --score_chunk is not given: the three autograd graphs of the FFHQ U-Net cost 3.45 GiB
-    per chain at 256 x 256 / 128 channels with the fused glue kernels; scaled by resolution and
-    width for other configs, with 12 % headroom."""
+def auto_score_chunk(opt, device, probe, world=1):
+    """Chains per score call when --score_chunk is not given.  Called AFTER the networks are on the device: `probe()` runs
+    one decode + gradient of ONE chain through the engine the run will use (pixel path: three U-Net autograd graphs,
+    3.45 GiB at FFHQ size; latent path: a no-grad LDM U-Net ladder + the VQ-f4 decoder's graph at 256 x 256), the peak it
+    adds is the per-chain cost, and the free memory left -- divided by the ranks that share the card in a shared-GPU
+    rehearsal (NHMC_SHARED_GPU=1) -- is filled to 1 / 1.12."""
     if opt.score_chunk:
         return opt.score_chunk
-    size = config['data']['image_size']
-    width = config['model'].get('num_channels', 128) if isinstance(config.get('model'), dict) else 128
-    per_chain = 3.45 * (size / 256) ** 2 * (width / 128) * 1.12
-    free = torch.cuda.mem_get_info(device)[0] / 2 ** 30
-    return max(1, min(opt.chains, int(free / per_chain)))
+    torch.cuda.synchronize(device)
+    torch.cuda.reset_peak_memory_stats(device)
+    base = torch.cuda.memory_allocated(device)
+    probe()
+    torch.cuda.synchronize(device)
+    per_chain = max(1, torch.cuda.max_memory_allocated(device) - base)
+    torch.cuda.empty_cache()
+    sharers = world if os.environ.get('NHMC_SHARED_GPU') == '1' else 1
+    free = torch.cuda.mem_get_info(device)[0] / sharers
+    return max(1, min(opt.chains, int(free / (per_chain * 1.12))))
+
+
+def run_with_oom_backoff(opt, run):
+    """run() with the score chunk halved after an out-of-memory error (a wrong estimate must not abort a run that
+    takes hours).  Local to the rank: the sampler has no collective inside a run, so ranks need not agree."""
+    import gc
+    while True:
+        try:
+            return run()
+        except torch.OutOfMemoryError:
+            chunk = opt.score_chunk or opt.chains
+            if chunk <= 1:
+                raise
+            opt.score_chunk = (chunk + 1) // 2
+            gc.collect()
+            torch.cuda.empty_cache()
+            print(f'[nhmc] out of memory at {chunk} chains per score call; retrying with --score_chunk {opt.score_chunk}',
+                  file=sys.stderr, flush=True)
 
 
 def image_generator(seed, s):
@@ -163,7 +189,6 @@ def _setup(opt, latent):
         opt.philox = True
     if opt.philox:
         opt.philox_seed = opt.seed
-    opt.score_chunk = auto_score_chunk(opt, config, device)
     opt.quiet = opt.chains > 1 or rank != 0
     opt.progress_every = 10 if rank == 0 else 0                           # stderr heartbeat for long quiet runs
     skip = opt.num_timesteps // (opt.timesteps + 1)                          # main_sampling.py:469-471
@@ -204,6 +229,18 @@ def main(argv=None):
     mc.pop('var_type', None)
     model = unet.create_model(**mc).to(device).eval().requires_grad_(False)
     algo = plugin.HMC(model, op, opt.sigma_0)
+    d = config['diffusion']
+    b = torch.from_numpy(schedule.get_beta_schedule(d['beta_schedule'], beta_start=d['beta_start'], beta_end=d['beta_end'],
+                                                    num_diffusion_timesteps=d['num_diffusion_timesteps'])).float().to(device)
+
+    def probe():
+        eng = sampler.LeapfrogEngine(algo.score, op, b, seq, seq_next, device)
+        eng.decode_and_grad(torch.zeros(1, ch, size, size, device=device), torch.zeros(1, op.M, device=device))
+    if world > 1 and rank != 0:
+        sharding.barrier()                                               # rank 0 probes (and fills MIOpen's cache) first
+    opt.score_chunk = auto_score_chunk(opt, device, probe, world)
+    if world > 1 and rank == 0:
+        sharding.barrier()
     if world > 1:
         # the first score-network call on a machine fills MIOpen's on-disk kernel cache (~1 min): one rank does it at
         # the shape the run will use, the others wait instead of racing through the same compiles
@@ -215,9 +252,6 @@ def main(argv=None):
             torch.autograd.grad(out, xw, torch.ones_like(out))
             torch.cuda.synchronize()
         sharding.barrier()
-    d = config['diffusion']
-    b = torch.from_numpy(schedule.get_beta_schedule(d['beta_schedule'], beta_start=d['beta_start'], beta_end=d['beta_end'],
-                                                    num_diffusion_timesteps=d['num_diffusion_timesteps'])).float().to(device)
     rows = []
     for batch in image_batches(images.shape[0], rank, world, opt.chains):
         x_orig = images[batch[0]:batch[-1] + 1].to(device).contiguous()
@@ -226,7 +260,7 @@ def main(argv=None):
         y_0 = torch.stack([d_[0] for d_ in drawn]).contiguous()
         x = torch.stack([d_[1] for d_ in drawn]).contiguous()
         opt.chain_id0 = batch[0]
-        out = sampler.hmc(x, n, b, seq, seq_next, algo, opt, y_0, op, x_orig)
+        out = run_with_oom_backoff(opt, lambda: sampler.hmc(x, n, b, seq, seq_next, algo, opt, y_0, op, x_orig))
         samples = out[None] if n == 1 else out                              # [n, 20, C, H, W]
         for k, s in enumerate(batch):
             rows.append(_psnr_row(s, samples[k], x_orig[k:k + 1]))
@@ -246,6 +280,13 @@ def main_latent(argv=None):
     model = ldm.create_latent_model(config['model'], ckpt='models/ldm/model.ckpt', quiet=rank != 0).to(device)
     algo = plugin.HMCLatent(model, op, opt.sigma_0)
     zc, zs = model.channels, model.image_size
+
+    def probe():
+        table = torch.cat([model.alphas_cumprod_prev[0:1], model.alphas_cumprod], dim=0)
+        eng = sampler.LeapfrogEngine(algo.score, op, None, seq, seq_next, device, alpha_table=table,
+                                     image_map=model.differentiable_decode_first_stage)
+        eng.decode_and_grad(torch.zeros(1, zc, zs, zs, device=device), torch.zeros(1, op.M, device=device))
+    opt.score_chunk = auto_score_chunk(opt, device, probe, world)
     if world > 1:
         sharding.barrier()
     rows = []
@@ -256,7 +297,7 @@ def main_latent(argv=None):
         y_0 = torch.stack([d_[0] for d_ in drawn]).contiguous()
         x = torch.stack([d_[1] for d_ in drawn]).contiguous()
         opt.chain_id0 = batch[0]
-        out = sampler.hmc_latent(x, n, seq, seq_next, algo, opt, y_0, op, x_orig)
+        out = run_with_oom_backoff(opt, lambda: sampler.hmc_latent(x, n, seq, seq_next, algo, opt, y_0, op, x_orig))
         per_chain = [out] if n == 1 else out                               # latents [<=10, C, h, w] per chain
         for k, s in enumerate(batch):
             imgs = model.decode_first_stage(per_chain[k]) if per_chain[k].shape[0] else per_chain[k]

@@ -404,6 +404,80 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_sr(
   if (threadIdx.x == 0) loss_ws[(int64_t)chain * gridDim.x + blockIdx.x] = v[0];
 }
 
+// The same for R = 4 (BASELINE configs[2]) with ONE float4 per thread and stream.  The form above gives a thread the 4
+// rows of its strip (8 streaming loads, 16 elements with two correctly rounded divisions each before its first store):
+// measured 37.9 us at 64 chains = 0.67 of the HBM peak, where the inpainting kernel, same traffic and arithmetic with
+// one float4 per thread, reaches 0.74.  Here the 4 waves of a block take the 4 rows of 64 blocks-of-pixels: lane = strip
+// (a wave instruction still covers 1 KiB of one image row when dim = 256), wave = row inside the block.  The clipped
+// decodes meet in LDS (4 KB) and every thread adds the 16 values of its block in the order of the form above -- row by
+// row, left to right -- so block means, residuals, loss and gradients are the same bits.  grid = (tiles of a plane,
+// plane, chain): no 64-bit division.
+__global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_sr4(
+    const float4* __restrict__ xt, const float4* __restrict__ e, int e_channels, const float* __restrict__ at,
+    const float* __restrict__ at_next, const float* __restrict__ y, float4* __restrict__ g_xt,
+    float4* __restrict__ g_e, double* __restrict__ loss_ws, int dim, int channels) {
+  constexpr int R = 4;
+  __shared__ float4 dec[R][NHMC_WAVE];
+  const int chain = blockIdx.z, plane = blockIdx.y;
+  const int lane = threadIdx.x & 63, rr = threadIdx.x >> 6;
+  const int w4 = dim / 4, yd = dim / R;
+  const int items = yd * w4;                                   // (output row, strip) pairs of one plane
+  const int item = blockIdx.x * NHMC_WAVE + lane;
+  const bool live = item < items;
+  const int it = live ? item : 0;
+  const int i = it / w4, s = it - i * w4;                     // R = 4: strip s is output column s
+  const float yv = live ? y[((int64_t)chain * channels + plane) * (int64_t)yd * yd + (int64_t)i * yd + s] : 0.0f;
+  const int64_t row = (int64_t)(i * R + rr) * w4 + s;
+  const int64_t xoff = ((int64_t)chain * channels + plane) * (int64_t)dim * w4 + row;
+  const int64_t eoff = ((int64_t)chain * e_channels + plane) * (int64_t)dim * w4 + row;
+  const Coef k = coef(at, at_next, chain);
+  float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), ev = xv;
+  if (live) { xv = nhmc_ldnt(&xt[xoff]); ev = nhmc_ldnt(&e[eoff]); }
+  const float* xe = reinterpret_cast<const float*>(&xv);
+  const float* ee = reinterpret_cast<const float*>(&ev);
+  float mp[4], mu[4];
+  float4 cl;
+  float* cle = reinterpret_cast<float*>(&cl);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float u = (xe[c] - ee[c] * k.c1) / k.c2;
+    const float pre = k.c3 * nhmc_clip1(u) + k.c4 * ee[c];
+    cle[c] = nhmc_clip1(pre);
+    mp[c] = nhmc_in1(pre);
+    mu[c] = nhmc_in1(u);
+  }
+  dec[rr][lane] = cl;
+  __syncthreads();
+  float bs = 0.0f;
+#pragma unroll
+  for (int r2 = 0; r2 < R; ++r2) {
+    const float4 d = dec[r2][lane];
+    bs += d.x; bs += d.y; bs += d.z; bs += d.w;
+  }
+  const float inv = 1.0f / (float)(R * R);
+  const float resid = live ? yv - bs * inv : 0.0f;
+  const float acc = rr == 0 ? resid * resid : 0.0f;            // one thread per block of pixels contributes to the loss
+  if (live) {
+    float4 ox, oe;
+    float* gx = reinterpret_cast<float*>(&ox);
+    float* gee = reinterpret_cast<float*>(&oe);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float gin = (-(2.0f * resid)) * inv;
+      gin = gin * mp[c];
+      const float gu = ((gin * k.c3) * mu[c]) / k.c2;
+      gx[c] = gu;
+      gee[c] = k.c4 * gin + (-gu) * k.c1;
+    }
+    nhmc_stnt(&g_xt[xoff], ox);
+    nhmc_stnt(&g_e[eoff], oe);
+  }
+  __shared__ double red[4];
+  double v[1] = {(double)acc};
+  nhmc_block_sum<1>(v, red);
+  if (threadIdx.x == 0) loss_ws[((int64_t)chain * gridDim.y + plane) * gridDim.x + blockIdx.x] = v[0];
+}
+
 bool bad_shape(int n_chains, int channels, int64_t hw, int e_channels) {
   return n_chains <= 0 || n_chains > 65535 || channels <= 0 || hw <= 0 ||
          (e_channels != channels && e_channels != 2 * channels);
@@ -519,6 +593,11 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int
   return nhmc_launch_status();
 }
 
+extern "C" int nhmc_sr_vjp_tiles(int channels, int dim, int ratio) {
+  if (ratio == 4) return channels * (((dim / 4) * (dim / 4) + NHMC_WAVE - 1) / NHMC_WAVE);
+  return nhmc_sr_tiles(channels, dim, ratio);
+}
+
 extern "C" int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_channels, const float* at,
                                     const float* at_next, const float* y, int ratio, float* g_xt, float* g_e,
                                     double* loss_ws, int n_chains, int channels, int dim, nhmc_stream_t stream) {
@@ -526,6 +605,13 @@ extern "C" int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_chann
   if (dim <= 0 || (dim % 4) || bad_shape(n_chains, channels, (int64_t)dim * dim, e_channels)) return NHMC_ERR_SHAPE;
   if (!(ratio == 2 || ratio == 4 || ratio == 8 || ratio == 16) || (dim % ratio)) return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e)) return NHMC_ERR_ALIGN;
+  if (ratio == 4 && channels <= 65535) {
+    const int per_plane = ((dim / 4) * (dim / 4) + NHMC_WAVE - 1) / NHMC_WAVE;
+    NHMC_LAUNCH(k_mix_bwd_sr4, dim3((unsigned)per_plane, (unsigned)channels, (unsigned)n_chains), dim3(NHMC_BLOCK), 0,
+                nhmc_s(stream), (const float4*)xt, (const float4*)e, e_channels, at, at_next, y, (float4*)g_xt,
+                (float4*)g_e, loss_ws, dim, channels);
+    return nhmc_launch_status();
+  }
   dim3 grid((unsigned)nhmc_sr_tiles(channels, dim, ratio), (unsigned)n_chains), block(NHMC_BLOCK);
 #define NHMC_BSR(R)                                                                                              \
   NHMC_LAUNCH(k_mix_bwd_sr<R>, grid, block, 0, nhmc_s(stream), (const float4*)xt, (const float4*)e, e_channels, \

@@ -97,17 +97,20 @@ __global__ void k_variance_keys(const float* __restrict__ m2, float div, float* 
   if (i <= n_chains) offsets[i] = (int32_t)(i * n_elem);
 }
 
+// The mass of the element of rank r is a constant of (r, N): the caller hands in std_table[r] = sqrt(M_r) and
+// inv_table[r] = 1 / M_r with M_r = exp(2 r/(N-1) - 1), evaluated ON THE HOST with the reference's own tensor
+// expressions (main_sampling.py:863-868), so the transcendental is the reference host's libm and not this GPU's expf
+// (whose last bit differs and which a 183-trajectory run amplifies to 1e-3).
 __global__ void k_mass_from_ranks(const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ flags,
+                                  const float* __restrict__ std_table, const float* __restrict__ inv_table,
                                   float* __restrict__ inv_m, float* __restrict__ std_m, int64_t n_elem) {
   const int chain = blockIdx.y;
   if (flags && !flags[chain]) return;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_elem) return;
   const int64_t idx = sorted_idx[(int64_t)chain * n_elem + r];
-  const float score = 2.0f * ((float)r / (float)(n_elem - 1)) - 1.0f;     // 2.0 * (ranks / (N - 1)) - 1.0
-  const float M = expf(score);                                            // k = 1
-  std_m[(int64_t)chain * n_elem + idx] = sqrtf(M);
-  inv_m[(int64_t)chain * n_elem + idx] = 1.0f / M;
+  std_m[(int64_t)chain * n_elem + idx] = std_table[r];
+  inv_m[(int64_t)chain * n_elem + idx] = inv_table[r];
 }
 
 __global__ void k_schedule_begin_mass(const int32_t* __restrict__ epoch, double* __restrict__ tau, double* __restrict__ eps,
@@ -179,9 +182,10 @@ extern "C" size_t nhmc_mass_sort_ws_bytes(int n_chains, int64_t n_elem) {
   return 4 * align_up(tot * 4) + align_up((size_t)(n_chains + 1) * 4) + align_up(cub_temp_bytes(n_chains, n_elem));
 }
 
-extern "C" int nhmc_mass_from_variance(const float* m2, int L, const int32_t* flags, float* inv_m, float* std_m,
-                                       void* ws, size_t ws_bytes, int n_chains, int64_t n_elem, nhmc_stream_t stream) {
-  if (!m2 || !inv_m || !std_m || !ws || n_chains <= 0 || n_elem <= 1) return NHMC_ERR_ARG;
+extern "C" int nhmc_mass_from_variance(const float* m2, int L, const int32_t* flags, const float* std_table,
+                                       const float* inv_table, float* inv_m, float* std_m, void* ws, size_t ws_bytes,
+                                       int n_chains, int64_t n_elem, nhmc_stream_t stream) {
+  if (!m2 || !std_table || !inv_table || !inv_m || !std_m || !ws || n_chains <= 0 || n_elem <= 1) return NHMC_ERR_ARG;
   if (n_chains > 65535 || (int64_t)n_chains * n_elem > 0x7fffffffLL) return NHMC_ERR_SHAPE;
   if (ws_bytes < nhmc_mass_sort_ws_bytes(n_chains, n_elem)) return NHMC_ERR_ARG;
   hipStream_t st = nhmc_s(stream);
@@ -202,7 +206,7 @@ extern "C" int nhmc_mass_from_variance(const float* m2, int L, const int32_t* fl
                                                   offsets, offsets + 1, 0, 32, st) != hipSuccess)
     return NHMC_ERR_LAUNCH;
   NHMC_LAUNCH(k_mass_from_ranks, dim3((unsigned)((n_elem + 255) / 256), (unsigned)n_chains), dim3(256), 0, st, vals_out,
-              flags, inv_m, std_m, n_elem);
+              flags, std_table, inv_table, inv_m, std_m, n_elem);
   return nhmc_launch_status();
 }
 

@@ -654,20 +654,29 @@ extern "C" int nhmc_data_spectral_proj_vjp(const float* xt_next, const float* y_
 }
 
 // ---- separable strided convolution (SRConv, obs_functions/Hfuncs.py:527-607) ----------------------------------
-// H(X) = A X A^T with A [sd][d] (the truncated-SVD form of the 1-D strided kernel matrix); H^T(Y) = A^T Y A;
-// H^+(Y) = A+ Y A+^T.  All three are two products of the same kernel:  OUT = IN^T S.
-//   nhmc_sandwich_rect: out = M1^T-chain generic:  t = in^T S1 ([R1][C1]),  out = t^T S2 ([C1][C2]).
-extern "C" int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, float* out, float* tmp, int n_img,
-                                  int K1, int R1, int C1, int C2, nhmc_stream_t stream) {
+// The reference applies its SVD factors one after the other, each a rounded fp32 stage (H at Hfuncs.py:65-71 with
+// Vt :576-583, singulars :598-599, U :585-592):
+//     H(X)   = U  ( S o (V1^T X V1) ) U^T        V1 = V_small[:, :sd] ([d][sd]), U = U_small ([sd][sd]),
+//     H^T(Y) = V1 ( S o (U^T  Y U ) ) V1^T       S[i][j] = fl(s_i * s_j) (:560; thresholded singular values),
+//     H^+(Y) = V1 ( S+ o (U^T Y U ) ) V1^T       S+ = 1 / S where S != 0 (:82-88)
+// -- the Deblurring2D chain with rectangular factors and one multiplier map for all channels.  Round 2 collapsed the
+// factors into A = U diag(s) V1^T (two products); the stages are kept now because whole-run agreement with the
+// reference needs its rounding sequence, not only its mathematics.
+// All products are the one kernel form OUT = IN^T S:
+//   nhmc_sandwich_rect: t = in^T S1 ([R1][C1]),  out = (t^T S2) o mul ([C1][C2]; mul nullable) = (S1^T in S2) o mul.
+extern "C" int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, const float* mul, float* out,
+                                  float* tmp, int n_img, int K1, int R1, int C1, int C2, nhmc_stream_t stream) {
   if (!in || !S1 || !S2 || !out || !tmp) return NHMC_ERR_ARG;
   if (n_img <= 0 || n_img > 65535 || (K1 % 32) || (R1 % 32) || (C1 % 32) || (C2 % 32) || K1 <= 0 || R1 <= 0 || C1 <= 0 || C2 <= 0)
     return NHMC_ERR_SHAPE;
-  if (!nhmc_aligned16(in) || !nhmc_aligned16(S1) || !nhmc_aligned16(S2) || !nhmc_aligned16(out) || !nhmc_aligned16(tmp))
+  if (!nhmc_aligned16(in) || !nhmc_aligned16(S1) || !nhmc_aligned16(S2) || !nhmc_aligned16(out) || !nhmc_aligned16(tmp) ||
+      !nhmc_aligned16(mul))
     return NHMC_ERR_ALIGN;
   hipStream_t st = nhmc_s(stream);
   int rc;
   // t[R1][C1] = in[K1][R1]^T S1[K1][C1];   out[C1][C2] = t[R1][C1]^T S2[R1][C2]
   if ((rc = gemm_krc<EPI_NONE, false>(in, S1, tmp, nullptr, nullptr, nullptr, n_img, 1, K1, R1, C1, st))) return rc;
+  if (mul) return gemm_krc<EPI_MULD, false>(tmp, S2, out, mul, nullptr, nullptr, n_img, 1, R1, C1, C2, st);
   return gemm_krc<EPI_NONE, false>(tmp, S2, out, nullptr, nullptr, nullptr, n_img, 1, R1, C1, C2, st);
 }
 
@@ -676,53 +685,69 @@ extern "C" int nhmc_srconv_tiles(int channels, int small_dim) {
   return channels * t * t;
 }
 
-// Data term: r = y - A clip(xt) A^T, loss partials (nhmc_srconv_tiles per chain), g = -2 A^T r A (x) mask.
-// At: A^T as stored ([d][sd] row-major), A: [sd][d].  tmp: float[n_img*(d*sd + sd*sd + sd*d)].
-extern "C" int nhmc_data_srconv(const float* xt, const float* y, const float* At, const float* A, int apply_clip,
-                                float* g_xt, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
-                                int small_dim, nhmc_stream_t stream) {
-  if (!xt || !y || !At || !A || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
-  if (n_chains <= 0 || channels <= 0 || (int64_t)n_chains * channels > 65535 || (dim % 32) || (small_dim % 32) ||
-      dim <= 0 || small_dim <= 0)
-    return NHMC_ERR_SHAPE;
-  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y) || !nhmc_aligned16(At) || !nhmc_aligned16(A) || !nhmc_aligned16(g_xt) ||
-      !nhmc_aligned16(tmp))
-    return NHMC_ERR_ALIGN;
-  hipStream_t st = nhmc_s(stream);
-  const int n = n_chains * channels, d = dim, sd = small_dim;
-  float* T1 = tmp;                                    // [d][sd]
-  float* Rr = T1 + (int64_t)n * d * sd;               // [sd][sd]
-  float* T2 = Rr + (int64_t)n * sd * sd;              // [sd][d]
+namespace {
+struct SrconvFactors { const float *V1, *V1T, *U, *UT, *S; };   // [d][sd], [sd][d], [sd][sd], [sd][sd], [sd][sd]
+
+// r = y - U (S o (V1^T x V1)) U^T with loss partials; then H^T r through its four products, the last one with the
+// gradient epilogue (`vjp` == nullptr: g = -2 H^T r (x) clip mask of `mask_src` when given) or the last DDIM step's VJP.
+// tmp: float[n * (d*sd + 3*sd*sd)].
+template <bool PRECLIP>
+int srconv_chain(const float* x, const float* y, const SrconvFactors& f, const float* mask_or_xt, const VjpArgs* vjp,
+                 float* g_xt, double* loss_ws, float* tmp, int n, int channels, int d, int sd, hipStream_t st) {
+  float* T1 = tmp;                                    // [d][sd], later [sd][d]
+  float* Z = T1 + (int64_t)n * d * sd;                // [sd][sd]
+  float* T2 = Z + (int64_t)n * sd * sd;               // [sd][sd]
+  float* Rr = T2 + (int64_t)n * sd * sd;              // [sd][sd]
   int rc;
-  if (apply_clip) { if ((rc = gemm_krc<EPI_NONE, true>(xt, At, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc; }
-  else            { if ((rc = gemm_krc<EPI_NONE, false>(xt, At, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc; }
-  if ((rc = gemm_krc<EPI_RESID, false>(T1, At, Rr, nullptr, y, loss_ws, n, channels, d, sd, sd, st))) return rc;   // r = y - A X A^T
-  if ((rc = gemm_krc<EPI_NONE, false>(Rr, A, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;  // r^T A
-  return gemm_krc<EPI_GRAD, false>(T2, A, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, sd, d, d, st);  // A^T r A
+  if ((rc = gemm_krc<EPI_NONE, PRECLIP>(x, f.V1, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc;   // (V1^T x)^T
+  if ((rc = gemm_krc<EPI_MULD, false>(T1, f.V1, Z, f.S, nullptr, nullptr, n, 1, d, sd, sd, st))) return rc;              // S o (V1^T x V1)
+  if ((rc = gemm_krc<EPI_NONE, false>(Z, f.UT, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, sd, st))) return rc;  // (U Z)^T
+  if ((rc = gemm_krc<EPI_RESID, false>(T2, f.UT, Rr, nullptr, y, loss_ws, n, channels, sd, sd, sd, st))) return rc;      // r = y - U Z U^T
+  if ((rc = gemm_krc<EPI_NONE, false>(Rr, f.U, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, sd, st))) return rc;  // (U^T r)^T
+  if ((rc = gemm_krc<EPI_MULD, false>(T2, f.U, Z, f.S, nullptr, nullptr, n, 1, sd, sd, sd, st))) return rc;              // S o (U^T r U)
+  if ((rc = gemm_krc<EPI_NONE, false>(Z, f.V1T, T1, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;  // (V1 W)^T
+  if (vjp) return gemm_krc<EPI_VJP, false>(T1, f.V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, sd, d, d, st, *vjp);
+  return gemm_krc<EPI_GRAD, false>(T1, f.V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, sd, d, d, st);
+}
+
+bool srconv_bad_shape(int n_chains, int channels, int dim, int small_dim) {
+  return n_chains <= 0 || channels <= 0 || (int64_t)n_chains * channels > 65535 || (dim % 32) || (small_dim % 32) ||
+         dim <= 0 || small_dim <= 0 || small_dim > dim;
+}
+}  // namespace
+
+// Data term: r = y - H(clip(xt)), loss partials (nhmc_srconv_tiles per chain), g = -2 H^T r (x) clip mask.
+extern "C" int nhmc_data_srconv(const float* xt, const float* y, const float* V1, const float* V1T, const float* U,
+                                const float* UT, const float* S, int apply_clip, float* g_xt, double* loss_ws, float* tmp,
+                                int n_chains, int channels, int dim, int small_dim, nhmc_stream_t stream) {
+  if (!xt || !y || !V1 || !V1T || !U || !UT || !S || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
+  if (srconv_bad_shape(n_chains, channels, dim, small_dim)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y) || !nhmc_aligned16(V1) || !nhmc_aligned16(V1T) || !nhmc_aligned16(U) ||
+      !nhmc_aligned16(UT) || !nhmc_aligned16(S) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(tmp))
+    return NHMC_ERR_ALIGN;
+  const SrconvFactors f{V1, V1T, U, UT, S};
+  const int n = n_chains * channels;
+  if (apply_clip)
+    return srconv_chain<true>(xt, y, f, xt, nullptr, g_xt, loss_ws, tmp, n, channels, dim, small_dim, nhmc_s(stream));
+  return srconv_chain<false>(xt, y, f, nullptr, nullptr, g_xt, loss_ws, tmp, n, channels, dim, small_dim, nhmc_s(stream));
 }
 
 // Same with the VJP of the last DDIM step applied in the last product's epilogue (xt_next = the clipped decode).
-extern "C" int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* At, const float* A,
-                                    const float* xt, const float* e, int e_channels, const float* at,
-                                    const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
-                                    int n_chains, int channels, int dim, int small_dim, nhmc_stream_t stream) {
-  if (!xt_next || !y || !At || !A || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
+extern "C" int nhmc_data_srconv_vjp(const float* xt_next, const float* y, const float* V1, const float* V1T,
+                                    const float* U, const float* UT, const float* S, const float* xt, const float* e,
+                                    int e_channels, const float* at, const float* at_next, float* g_xt, float* g_e,
+                                    double* loss_ws, float* tmp, int n_chains, int channels, int dim, int small_dim,
+                                    nhmc_stream_t stream) {
+  if (!xt_next || !y || !V1 || !V1T || !U || !UT || !S || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
     return NHMC_ERR_ARG;
-  if (n_chains <= 0 || channels <= 0 || (int64_t)n_chains * channels > 65535 || (dim % 32) || (small_dim % 32) ||
-      dim <= 0 || small_dim <= 0 || (e_channels != channels && e_channels != 2 * channels))
+  if (srconv_bad_shape(n_chains, channels, dim, small_dim) || (e_channels != channels && e_channels != 2 * channels))
     return NHMC_ERR_SHAPE;
-  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y) || !nhmc_aligned16(At) || !nhmc_aligned16(A) ||
-      !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e) || !nhmc_aligned16(tmp))
+  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y) || !nhmc_aligned16(V1) || !nhmc_aligned16(V1T) || !nhmc_aligned16(U) ||
+      !nhmc_aligned16(UT) || !nhmc_aligned16(S) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(g_e) || !nhmc_aligned16(tmp))
     return NHMC_ERR_ALIGN;
-  hipStream_t st = nhmc_s(stream);
-  const int n = n_chains * channels, d = dim, sd = small_dim;
-  float* T1 = tmp;                                    // [d][sd]
-  float* Rr = T1 + (int64_t)n * d * sd;               // [sd][sd]
-  float* T2 = Rr + (int64_t)n * sd * sd;              // [sd][d]
-  int rc;
-  if ((rc = gemm_krc<EPI_NONE, false>(xt_next, At, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc;
-  if ((rc = gemm_krc<EPI_RESID, false>(T1, At, Rr, nullptr, y, loss_ws, n, channels, d, sd, sd, st))) return rc;
-  if ((rc = gemm_krc<EPI_NONE, false>(Rr, A, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;
+  const SrconvFactors f{V1, V1T, U, UT, S};
   const VjpArgs vj{e, g_e, at, at_next, e_channels};
-  return gemm_krc<EPI_VJP, false>(T2, A, g_xt, nullptr, xt, nullptr, n, channels, sd, d, d, st, vj);
+  return srconv_chain<false>(xt_next, y, f, xt, &vj, g_xt, loss_ws, tmp, n_chains * channels, channels, dim, small_dim,
+                             nhmc_s(stream));
 }

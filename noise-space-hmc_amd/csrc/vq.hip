@@ -43,8 +43,12 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
     zc[c] = live ? zp[(int64_t)c * hw] : 0.0f;
     zz = c == 0 ? zc[0] * zc[0] : zz + zc[c] * zc[c];
   }
+  // torch.argmin's answers for non-finite rows (a divergent trajectory decoded through the first stage): a NaN distance
+  // counts as the minimum and the FIRST one wins; an all-inf row has its first minimum at index 0.  `seen_nan` freezes
+  // the first NaN; the sentinel index of a wave that never updated is resolved after the merge.
   float best = INFINITY;
   int best_k = 0x7fffffff;
+  bool seen_nan = false;
   constexpr int QUARTER = VQ_CHUNK / 4;
   for (int k0 = 0; k0 < n_embed; k0 += VQ_CHUNK) {
     __syncthreads();
@@ -72,7 +76,10 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
       float ee = c4.w;
       if constexpr (D == 4) { dot = __fmaf_rn(zc[3], c4.w, dot); ee = norm[k]; }
       const float d = (zz + ee) - 2.0f * dot;
-      if (d < best) { best = d; best_k = k0 + k; }       // within a wave the code index only grows: first minimum kept
+      const bool dn = d != d;
+      if ((d < best) || (dn && !seen_nan)) {             // within a wave the code index only grows: first minimum kept
+        best = d; best_k = k0 + k; seen_nan = seen_nan || dn;
+      }
     }
   }
   part_d[part][lane] = best;
@@ -83,8 +90,10 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_vq_nearest(
   for (int w = 1; w < 4; ++w) {                          // first minimum over the whole codebook: smallest d, then smallest index
     const float d = part_d[w][lane];
     const int k = part_k[w][lane];
-    if (d < best || (d == best && k < best_k)) { best = d; best_k = k; }
+    const bool dn = d != d, bn = best != best;
+    if (dn ? (!bn || k < best_k) : (!bn && (d < best || (d == best && k < best_k)))) { best = d; best_k = k; }
   }
+  if ((unsigned)best_k >= (unsigned)n_embed) best_k = 0;   // no distance below +inf anywhere: argmin of an all-inf row
   if (idx_out) idx_out[p] = best_k;
   float* qp = z_q + b * D * hw + pos;
 #pragma unroll

@@ -269,7 +269,7 @@ def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None, loss_out=None):
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)          # the kernel writes channels [0, C) only
-    tiles = lib.nhmc_sr_tiles(Cc, dim, ratio)
+    tiles = lib.nhmc_sr_vjp_tiles(Cc, dim, ratio)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
     rc = lib.nhmc_ddim_mix_bwd_sr(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                   _p(y, torch.float32, 'y'), ratio, _p(g_xt), _p(g_e), _p(ws), B, Cc, dim, _stream())
@@ -278,7 +278,15 @@ def ddim_mix_bwd_sr(xt, e, at, at_next, y, ratio, g_e_out=None, loss_out=None):
 
 
 # ---- a12-a15 --------------------------------------------------------------------------------
+NO_LOSS = object()      # pass as loss_out: the per-chain loss is not wanted (a MID leapfrog step uses only the gradient)
+
+
 def sum_partials(ws, tiles, n_chains, stride=1, offset=0, out=None):
+    """Second pass of the two-pass loss: the tile partials of each chain added in a fixed order.  out=NO_LOSS skips the
+    launch and returns None -- the sampler reads the loss of a trajectory's first and last evaluation only
+    (main_sampling.py:697,717), so the L - 1 evaluations in between need the gradient alone."""
+    if out is NO_LOSS:
+        return None
     lib = _lib.load()
     if out is None:
         out = torch.empty(n_chains, dtype=torch.float64, device=ws.device)
@@ -355,8 +363,10 @@ def sr_Ht(y, ratio, channels, dim, scale):
     return x
 
 
-def _host_w(w):
-    """[V[0,0] .. V[C-1,0], s, U[0,0]]: the kernels read channels + 2 values."""
+def _host_w(w, channels):
+    """[V[0,0] .. V[C-1,0], s, U[0,0]]: the kernels read channels + 2 host floats (ABI 2; ABI 1 took `channels`)."""
+    if len(w) != channels + 2:
+        raise _lib.NhmcError(f'colorization weights: channels + 2 = {channels + 2} values (V[:,0], s, U[0,0]), got {len(w)}')
     arr = (C.c_float * len(w))(*[float(v) for v in w])
     return C.cast(arr, C.c_void_p), arr
 
@@ -368,7 +378,7 @@ def data_color(xt, y, w, apply_clip=True, loss_out=None):
     tiles = lib.nhmc_color_tiles(hw)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
     g = torch.empty_like(xt)
-    wp, keep = _host_w(w)
+    wp, keep = _host_w(w, Cc)
     rc = lib.nhmc_data_color(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), wp, int(apply_clip), _p(g), _p(ws),
                              B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_data_color')
@@ -384,7 +394,7 @@ def ddim_mix_bwd_color(xt, e, at, at_next, y, w, g_e_out=None, loss_out=None):
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)
-    wp, keep = _host_w(w)
+    wp, keep = _host_w(w, Cc)
     rc = lib.nhmc_ddim_mix_bwd_color(_p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
                                      _p(y, torch.float32, 'y'), wp, _p(g_xt), _p(g_e), _p(ws), B, Cc, hw, _stream())
     _lib.check(rc, 'nhmc_ddim_mix_bwd_color')
@@ -395,7 +405,7 @@ def color_H(x, w):
     lib = _lib.load()
     B, Cc, hw = x.shape[0], x.shape[1], x[0, 0].numel()
     y = torch.empty(B, hw, dtype=torch.float32, device=x.device)
-    wp, keep = _host_w(w)
+    wp, keep = _host_w(w, Cc)
     _lib.check(lib.nhmc_color_H(_p(x, torch.float32, 'x'), wp, _p(y), B, Cc, hw, _stream()), 'nhmc_color_H')
     return y
 
@@ -404,9 +414,7 @@ def color_Ht(y, w, channels, pinv=False):
     lib = _lib.load()
     B, hw = y.shape
     x = torch.empty(B, channels * hw, dtype=torch.float32, device=y.device)
-    if len(w) != channels + 2:
-        raise _lib.NhmcError('colorization weights: channels + 2 values (V[:,0], s, U[0,0])')
-    wp, keep = _host_w(w)
+    wp, keep = _host_w(w, channels)
     _lib.check(lib.nhmc_color_Ht(_p(y, torch.float32, 'y'), wp, int(pinv), _p(x), B, channels, hw, _stream()), 'nhmc_color_Ht')
     return x
 
@@ -475,49 +483,63 @@ def spectral_apply(x, L, R, Dmap, LoT, RoT):
     return out
 
 
-def sandwich_rect(x, S1, S2):
-    """x: [n_img, K1, R1]; t = x^T S1; out = t^T S2 -> [n_img, C1, C2]"""
+def sandwich_rect(x, S1, S2, mul=None):
+    """x: [n_img, K1, R1]; t = x^T S1; out = (t^T S2) o mul -> [n_img, C1, C2] = (S1^T x S2) o mul  (mul [C1, C2] or None)"""
     lib = _lib.load()
     n, K1, R1 = x.shape
     C1, C2 = S1.shape[1], S2.shape[1]
     if S1.shape[0] != K1 or S2.shape[0] != R1:
         raise _lib.NhmcError('sandwich_rect: factor shapes do not chain')
+    if mul is not None and tuple(mul.shape) != (C1, C2):
+        raise _lib.NhmcError('sandwich_rect: the multiplier map must be [C1, C2]')
     out = torch.empty(n, C1, C2, dtype=torch.float32, device=x.device)
     tmp = torch.empty(n, R1, C1, dtype=torch.float32, device=x.device)
-    rc = lib.nhmc_sandwich_rect(_p(x, torch.float32, 'x'), _p(S1, torch.float32), _p(S2, torch.float32), _p(out), _p(tmp),
-                                n, K1, R1, C1, C2, _stream())
+    rc = lib.nhmc_sandwich_rect(_p(x, torch.float32, 'x'), _p(S1, torch.float32), _p(S2, torch.float32), _p(mul, torch.float32, 'mul'),
+                                _p(out), _p(tmp), n, K1, R1, C1, C2, _stream())
     _lib.check(rc, 'nhmc_sandwich_rect')
     return out
 
 
-def data_srconv(xt, y, At, A, apply_clip=True, loss_out=None):
+def _srconv_factors(f, dim):
+    """f = (V1 [d, sd], V1T [sd, d], U [sd, sd], UT [sd, sd], S [sd, sd]) -> sd, after a shape check"""
+    V1, V1T, U, UT, S = f
+    sd = U.shape[0]
+    if tuple(V1.shape) != (dim, sd) or tuple(V1T.shape) != (sd, dim) or tuple(U.shape) != (sd, sd) or \
+            tuple(UT.shape) != (sd, sd) or tuple(S.shape) != (sd, sd):
+        raise _lib.NhmcError('SRConv factors: V1 [d, sd], V1^T [sd, d], U, U^T, S [sd, sd]')
+    return sd
+
+
+def data_srconv(xt, y, factors, apply_clip=True, loss_out=None):
+    """factors: (V1, V1T, U, UT, S) as nhmc.operators.SRConv keeps them -> (loss [B] float64, g_xt)"""
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
-    sd = A.shape[0]
+    sd = _srconv_factors(factors, dim)
     tiles = lib.nhmc_srconv_tiles(Cc, sd)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
-    tmp = torch.empty(B * Cc * (2 * dim * sd + sd * sd), dtype=torch.float32, device=xt.device)
+    tmp = torch.empty(B * Cc * (dim * sd + 3 * sd * sd), dtype=torch.float32, device=xt.device)
     g = torch.empty_like(xt)
-    rc = lib.nhmc_data_srconv(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(At, torch.float32), _p(A, torch.float32),
+    rc = lib.nhmc_data_srconv(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), *[_p(t, torch.float32) for t in factors],
                               int(apply_clip), _p(g), _p(ws), _p(tmp), B, Cc, dim, sd, _stream())
     _lib.check(rc, 'nhmc_data_srconv')
     return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_srconv_vjp(xt_next, y, At, A, xt, e, at, at_next, g_e_out=None, loss_out=None):
+def data_srconv_vjp(xt_next, y, factors, xt, e, at, at_next, g_e_out=None, loss_out=None):
     """Bicubic / strided-convolution data term on the clipped decode + VJP of the last DDIM step in the last product's
     epilogue -> (loss [B] float64, g_xt, g_e)."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
-    dim, sd = xt.shape[2], A.shape[0]
+    dim = xt.shape[2]
+    sd = _srconv_factors(factors, dim)
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     tiles = lib.nhmc_srconv_tiles(Cc, sd)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
-    tmp = torch.empty(B * Cc * (2 * dim * sd + sd * sd), dtype=torch.float32, device=xt.device)
+    tmp = torch.empty(B * Cc * (dim * sd + 3 * sd * sd), dtype=torch.float32, device=xt.device)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)
-    rc = lib.nhmc_data_srconv_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'), _p(At, torch.float32),
-                                  _p(A, torch.float32), _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec,
+    rc = lib.nhmc_data_srconv_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'),
+                                  *[_p(t, torch.float32) for t in factors], _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec,
                                   _p(at), _p(at_next), _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, sd, _stream())
     _lib.check(rc, 'nhmc_data_srconv_vjp')
     return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
@@ -671,13 +693,18 @@ def leapfrog_mass(mode, x, p, g, inv_m, eps, sigma_y, sums_ws=None, g2=None, z=N
     _lib.check(rc, 'nhmc_leapfrog_mass')
 
 
-def mass_from_variance(m2, L, flags, inv_m, std_m, ws=None):
+def mass_from_variance(m2, L, flags, inv_m, std_m, tables, ws=None):
+    """tables: (std_table, inv_table) float32 [N] on the device, by rank (nhmc.schedule.mass_tables(N, device))."""
     lib = _lib.load()
     B, N = _chains_elems(m2)
+    std_t, inv_t = tables
+    if std_t.numel() != N or inv_t.numel() != N:
+        raise _lib.NhmcError('mass tables must have one entry per element (rank)')
     need = lib.nhmc_mass_sort_ws_bytes(B, N)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=m2.device)
-    rc = lib.nhmc_mass_from_variance(_p(m2, torch.float32, 'm2'), int(L), _p(flags, torch.int32), _p(inv_m, torch.float32),
+    rc = lib.nhmc_mass_from_variance(_p(m2, torch.float32, 'm2'), int(L), _p(flags, torch.int32), _p(std_t, torch.float32, 'std_table'),
+                                     _p(inv_t, torch.float32, 'inv_table'), _p(inv_m, torch.float32),
                                      _p(std_m, torch.float32), _p(ws), ws.numel(), B, N, _stream())
     _lib.check(rc, 'nhmc_mass_from_variance')
     return ws

@@ -223,7 +223,13 @@ class Deblurring2D(H_functions):
     def project_observation(self, y):
         """y^ = U1^T y U2, cached per observation buffer: the sampler passes the same y_0 (or the same chunk views of it)
         in every leapfrog step of a run.  An entry pins the buffer's storage, so its address cannot be handed to another
-        tensor while the entry lives; an in-place write bumps the version and misses."""
+        tensor while the entry lives; an in-place write bumps the version and misses.
+        While the stream is being captured into a hipGraph the cache is bypassed in both directions: the projection must
+        be a launch OF the graph, because a replay refills the static observation buffer with another chunk's y (the
+        engine keys its graphs by shape, sampler.LeapfrogEngine._graphed_chunk) -- a cached y^ of the buffer's warm-up
+        content would silently serve every later chunk."""
+        if y.is_cuda and torch.cuda.is_current_stream_capturing():
+            return K.spectral_project(y, self._f(0), self._f(1))
         key = (y.data_ptr(), y._version, tuple(y.shape))
         hit = self._y_proj.get(key)
         if hit is None:
@@ -342,9 +348,14 @@ def strided_conv_matrix(kernel, img_dim, stride):
 
 
 class SRConv(H_functions):
-    """obs_functions/Hfuncs.py:527-607 (`sr_bicubicN`): H(X) = A X A^T per channel with A = U diag(s) V[:, :sd]^T the
-    SVD of the strided kernel matrix, singular values < 3e-2 zeroed (:557-558); here the channel interleave of the
-    singular values is consistent (`repeat_interleave`, :599), so the operator is the plain separable one."""
+    """obs_functions/Hfuncs.py:527-607 (`sr_bicubicN`), in the reference's stage order: with the SVD U diag(s) V^T of the
+    strided 1-D kernel matrix (singular values < 3e-2 zeroed, :557-558), V1 = V[:, :sd] and S[i][j] = s_i s_j (:560),
+
+        H(X) = U (S o (V1^T X V1)) U^T,   H^T(Y) = V1 (S o (U^T Y U)) V1^T,   H^+(Y) = V1 (S+ o (U^T Y U)) V1^T
+
+    per channel, every product and the multiplication by S a rounded fp32 stage as in H / Ht / H_pinv (:65-90) with
+    Vt / U / Ut / V (:566-596).  The channel interleave of the singular values is consistent here (`repeat_interleave`,
+    :599), so one multiplier map serves all channels."""
 
     def __init__(self, kernel, channels, img_dim, device, stride=1):
         Hs = strided_conv_matrix(kernel.detach().cpu().float(), img_dim, stride)
@@ -364,16 +375,15 @@ class SRConv(H_functions):
         self.small_dim = sd = img_dim // stride
         if img_dim % 32 or sd % 32:
             raise NhmcError('SRConv needs img_dim and img_dim/stride to be multiples of 32')
-        # the reference applies V^T, the singular values and U one after the other; collapsing them into A is done in
-        # float64 so that A carries one fp32 rounding per entry instead of a 64-term fp32 accumulation (the loss
-        # amplifies an operator perturbation by |H x| / |r|)
-        U, s, Vh = U.detach().cpu().double(), s.detach().cpu().double(), V.detach().cpu().double().t()[:sd]
-        s = torch.where(s < 3e-2, torch.zeros_like(s), s)           # :557-558
-        sinv = torch.where(s != 0, 1.0 / s, torch.zeros_like(s))
-        A = ((U * s) @ Vh).float()                                  # [sd, d]
-        Ap = ((Vh.t() * sinv) @ U.t()).float()                      # [d, sd]  pseudo-inverse
-        self.A, self.At = A.contiguous().to(device), A.t().contiguous().to(device)
-        self.ApT, self.Ap = Ap.t().contiguous().to(device), Ap.contiguous().to(device)
+        U, s, V = U.detach().cpu().float(), s.detach().cpu().float().clone(), V.detach().cpu().float()
+        s[s < 3e-2] = 0                                             # :557-558
+        S = torch.matmul(s.reshape(sd, 1), s.reshape(1, sd))        # :560, the reference's fp32 products
+        Sinv = S.clone()
+        Sinv[S != 0] = 1 / S[S != 0]                                # :85-86
+        V1 = V[:, :sd]
+        dev = lambda t: t.contiguous().to(device)
+        self.V1, self.V1T, self.U, self.UT, self.S, self.Sinv = dev(V1), dev(V1.t()), dev(U), dev(U.t()), dev(S), dev(Sinv)
+        self.factors = (self.V1, self.V1T, self.U, self.UT, self.S)
         self.M = channels * sd * sd
 
     def _planes(self, v, dim):
@@ -381,18 +391,22 @@ class SRConv(H_functions):
 
     def H(self, vec):
         B = vec.shape[0]
-        return K.sandwich_rect(self._planes(vec, self.img_dim), self.At, self.At).reshape(B, -1)       # A X A^T
+        z = K.sandwich_rect(self._planes(vec, self.img_dim), self.V1, self.V1, mul=self.S)         # S o (V1^T X V1)
+        return K.sandwich_rect(z, self.UT, self.UT).reshape(B, -1)                                  # U Z U^T
+
+    def _adjoint(self, vec, mul):
+        B = vec.shape[0]
+        w = K.sandwich_rect(self._planes(vec, self.small_dim), self.U, self.U, mul=mul)            # mul o (U^T Y U)
+        return K.sandwich_rect(w, self.V1T, self.V1T).reshape(B, -1)                               # V1 W V1^T
 
     def Ht(self, vec):
-        B = vec.shape[0]
-        return K.sandwich_rect(self._planes(vec, self.small_dim), self.A, self.A).reshape(B, -1)       # A^T Y A
+        return self._adjoint(vec, self.S)
 
     def H_pinv(self, vec):
-        B = vec.shape[0]
-        return K.sandwich_rect(self._planes(vec, self.small_dim), self.ApT, self.ApT).reshape(B, -1)   # A+ Y A+^T
+        return self._adjoint(vec, self.Sinv)
 
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
-        return K.data_srconv(xt, y.contiguous(), self.At, self.A, apply_clip, loss_out=loss_out)
+        return K.data_srconv(xt, y.contiguous(), self.factors, apply_clip, loss_out=loss_out)
 
     fused_wants_decode = True
 
@@ -400,7 +414,7 @@ class SRConv(H_functions):
         """Data term + VJP of the last DDIM step (in the last product's epilogue) -> (loss, g_xt, g_e)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
-        return K.data_srconv_vjp(xt_next, y.contiguous(), self.At, self.A, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
+        return K.data_srconv_vjp(xt_next, y.contiguous(), self.factors, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
 
 
 def bicubic_taps(factor, a=-0.5):

@@ -23,7 +23,7 @@ import torch
 
 from . import kernels as K
 from .plugin import HMC
-from .schedule import compute_alpha
+from .schedule import compute_alpha, mass_tables as _mass_tables
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -173,18 +173,22 @@ class LeapfrogEngine:
             K.grad_cache_store(ga, gb, loss[lo:hi], cache.g[:, lo:hi], cache.loss[:, lo:hi], cache.sel[lo:hi])
         cache.valid = True
 
-    def step(self, mode, x_in, x, p, y, eps, sigma_y, m_inv, ws, graph=False, cache=None):
+    def step(self, mode, x_in, x, p, y, eps, sigma_y, m_inv, ws, graph=False, cache=None, want_loss=None):
         """Decode + gradient at x_in, then the fused leapfrog update of (x, p), chunk by chunk: every kernel writes
         its slice of the batch-wide outputs and each chunk's two gradient pieces go straight into the update --
         no gather copies, no clone of the position.  mode FIRST: out of place (x_in -> x, x_in kept); MID / LAST:
         x_in is x.  cache (a GradCache, LAST only): the end point's loss and summed gradient are also stored in the
-        chains' free cache slots.  -> (xt, loss): batch-wide buffers owned by the engine, valid until the next step."""
+        chains' free cache slots.  want_loss (default: every mode but MID): the per-chain loss is summed from the data term's
+        tile partials only when somebody reads it -- the Hamiltonians at a trajectory's two ends (main_sampling.py:697,717);
+        a MID step needs the gradient alone and skips that launch (its `loss` return is then stale).
+        -> (xt, loss): batch-wide buffers owned by the engine, valid until the next step."""
         B, N = x.shape[0], x[0].numel()
         xt_out, loss = self._out_buffers(x)
+        want_loss = (mode != K.LF_MID) if want_loss is None else want_loss
         tiles2 = 2 * K.leapfrog_tiles(N)
         run = self._graphed_chunk if graph else self._decode_and_grad_chunk
         for lo, hi in self._chunks(B):
-            ga, gb = run(x_in[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi])
+            ga, gb = run(x_in[lo:hi], y[lo:hi], xt_out[lo:hi], loss[lo:hi] if want_loss else K.NO_LOSS)
             w = ws[lo * tiles2: hi * tiles2]
             if self.update_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), hi - lo)
@@ -222,7 +226,8 @@ class LeapfrogEngine:
         sy.copy_(y)
         g.replay()
         xt_out.copy_(sxt)
-        loss_out.copy_(sloss)
+        if loss_out is not K.NO_LOSS:
+            loss_out.copy_(sloss)
         return grads                                            # the graph's own buffers: valid until its next replay
 
     def _decode_and_grad_chunk(self, x, y, xt_out, loss_out):
@@ -551,7 +556,7 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
 # diagonal-mass variant
 # --------------------------------------------------------------------------------------------- #
 def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, burn=5, epochs=40,
-                    sampling=10, chunk=None, max_iters=None, collect_trace=False):
+                    sampling=10, chunk=None, max_iters=None, collect_trace=False, mass_tables=None):
     """Per-chain form of `hmc_test_conditioning` (main_sampling.py:776-894): HMC with a diagonal mass rebuilt from
     the rank transform of each accepted trajectory's position variance.  Returns SimpleNamespace(samples
     [B, 4*sampling-sampling... = total-(epochs+sampling), C, H, W], x, epoch, n_accept, n_reject, iters, trace)."""
@@ -577,6 +582,10 @@ def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *
     mean, m2 = torch.zeros_like(x), torch.zeros_like(x)
     samples = torch.zeros((B, n_keep) + tuple(x.shape[1:]), dtype=torch.float32, device=device)
     ws, sort_ws = K.leapfrog_ws(B, N, device), None
+    # sqrt(M_r), 1 / M_r by rank r: constants of N, built once with the reference's own tensor expressions (:863-868).
+    # mass_tables = (std, inv) overrides them (a parity test hands in the tables of the host the reference ran on).
+    tables = tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in mass_tables) if mass_tables is not None \
+        else _mass_tables(N, device)
     trace = [] if collect_trace else None
     it = 0
     while True:
@@ -597,7 +606,7 @@ def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *
         accept, dH = K.metropolis(H0, H1, u, st['active'])
         # mass rebuild for accepted chains past epochs//3 (pre-increment epoch, :857)
         flags = (accept * (st['epoch'] > epochs // 3).int()).contiguous()
-        sort_ws = K.mass_from_variance(m2, L, flags, inv_m, std_m, sort_ws)
+        sort_ws = K.mass_from_variance(m2, L, flags, inv_m, std_m, tables, sort_ws)
         K.accept_commit(accept, st['epoch'], x, x_prop, xt, samples, epochs + sampling - n_keep, n_keep)
         epoch_before = st['epoch'].clone() if collect_trace else None
         K.schedule_end(accept, st)

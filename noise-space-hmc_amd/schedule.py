@@ -68,3 +68,13 @@ def timestep_ladder(num_timesteps=1000, timesteps=3):
     skip = num_timesteps // (timesteps + 1)
     seq = list(range(skip, num_timesteps, skip))
     return seq, [-1] + seq[:-1]
+
+
+def mass_tables(n_elem, device, k=1):
+    """(std_table, inv_table) by rank r for the diagonal-mass sampler (nhmc_mass_from_variance): sqrt(M_r) and 1 / M_r
+    of M_r = exp(k (2 r/(N-1) - 1)), evaluated once on the host with the reference's own tensor expressions
+    (main_sampling.py:863-868) -- host constants of N, like the alpha-bar table."""
+    ranks = torch.arange(n_elem, dtype=torch.float)
+    scores = 2.0 * (ranks / (n_elem - 1)) - 1.0
+    M = torch.exp(k * scores)
+    return torch.sqrt(M).to(device), (1.0 / M).to(device)

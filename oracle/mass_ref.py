@@ -13,8 +13,10 @@ import torch
 from .hmc_ref import _data_loss_and_grad
 
 
-def mass_from_variance(M2, L, k=1, stable=False):
+def mass_from_variance(M2, L, k=1, stable=False, tables=None):
     """main_sampling.py:858-870 for one flattened chain: -> (M, std, inv_M), all [N].
+    tables (optional): (M_by_rank, std_by_rank) of the host the reference ran on (fixture G11b) in place of this
+    host's torch.exp / torch.sqrt -- M is a function of the rank alone.
 
     The reference sorts with torch's default UNSTABLE sort (:860), so among equal variances -- e.g. the all-zero
     variance of epochs 14..18, before the Welford accumulation starts -- the rank order is whatever the sort
@@ -24,6 +26,9 @@ def mass_from_variance(M2, L, k=1, stable=False):
     _, sorted_idx = torch.sort(variance, stable=stable)
     ranks = torch.zeros_like(sorted_idx, dtype=torch.float)
     ranks[sorted_idx] = torch.arange(len(variance), dtype=torch.float)
+    if tables is not None:
+        M, std = tables[0][ranks.long()], tables[1][ranks.long()]
+        return M, std, 1.0 / M
     scores = 2.0 * (ranks / (variance.numel() - 1)) - 1.0
     M = torch.exp(k * scores)
     return M, torch.sqrt(M), 1.0 / M
@@ -36,7 +41,7 @@ def sigma_y_mass(epoch, sigma_0, burn=5, epochs=40):
 
 
 def hmc_mass_reference(x, b, seq, seq_next, model, Hop, y_0, x_orig, *, tau, epsilon, sigma_0, burn=5, epochs=40,
-                       sampling=10, trace=None, stable_sort=False):
+                       sampling=10, trace=None, stable_sort=False, tables=None):
     """Batch-1 loop of main_sampling.py:776-894 with the reference's RNG call order."""
     x = x.detach().requires_grad_()
     L = max(1, math.floor(tau / epsilon))
@@ -81,7 +86,7 @@ def hmc_mass_reference(x, b, seq, seq_next, model, Hop, y_0, x_orig, *, tau, eps
             trace.setdefault('epoch', []).append(epoch)
         if accept:
             if epoch > epochs // 3:
-                _, std_diag, inv_M = mass_from_variance(M2, L, stable=stable_sort)
+                _, std_diag, inv_M = mass_from_variance(M2, L, stable=stable_sort, tables=tables)
             rejected = 0
             if epoch >= epochs + sampling:
                 finals.append(xt.clone()[0])

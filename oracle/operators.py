@@ -228,10 +228,16 @@ class WalshHadamardRef:
 
 
 class SeparableStridedRef:
-    """Hfuncs.py:527-607 (SRConv): H(X) = A X A^T with A = U diag(s) V[:, :sd]^T of the strided 1-D kernel matrix
-    (reflective padding :547-551; s < 3e-2 zeroed :557-558); H^T(Y) = A^T Y A; H^+(Y) = A+ Y A+^T."""
+    """Hfuncs.py:527-607 (SRConv) in the reference's stage order.  With U diag(s) V^T the SVD of the strided 1-D kernel
+    matrix (reflective padding :547-551; s < 3e-2 zeroed :557-558), V1 = V[:, :sd], S = s s^T (:560):
+        H(X)   = U (S o (V1^T X V1)) U^T     (H :65-71 = U(singulars * Vt(x)); Vt :576-583 multiplies from the left first,
+        H^T(Y) = V1 (S o (U^T Y U)) V1^T      then from the right; U :585-592, Ut :594-596, V :566-574 likewise)
+        H^+(Y) = V1 (S+ o (U^T Y U)) V1^T    (S+ = 1 / S where S != 0, :82-88)
+    The top-left sd x sd block the reference's permutation selects (:563-564) is the product with V1; its entries are
+    the same dot products, so slicing before or after the matmul changes nothing.  On this torch build the three maps
+    reproduce G10 bit for bit."""
 
-    def __init__(self, kernel, channels, img_dim, stride):
+    def __init__(self, kernel, channels, img_dim, stride, svd=None):
         self.channels, self.img_dim, self.small_dim = channels, img_dim, img_dim // stride
         k, sd = kernel.shape[0], self.small_dim
         Hs = torch.zeros(sd, img_dim)
@@ -243,24 +249,40 @@ class SeparableStridedRef:
                 if je >= img_dim:
                     je = (img_dim - 1) - (je - img_dim)
                 Hs[i // stride, je] += kernel[j - i + k // 2]
-        U, s, V = torch.svd(Hs, some=False)
-        s = torch.where(s < 3e-2, torch.zeros_like(s), s)
-        sinv = torch.where(s != 0, 1 / s, torch.zeros_like(s))
-        self.A = (U * s) @ V[:, :sd].t()
-        self.Ap = (V[:, :sd] * sinv) @ U.t()
+        U, s, V = svd if svd is not None else torch.svd(Hs, some=False)       # svd: a reference instance's exported factors
+        s = s.clone()
+        s[s < 3e-2] = 0
+        self.U, self.V = U, V                                       # V: full [d, d], as the reference multiplies by it
+        self.S = torch.matmul(s.reshape(sd, 1), s.reshape(1, sd))
+        self.Sinv = self.S.clone()
+        self.Sinv[self.S != 0] = 1 / self.S[self.S != 0]
         self.M = channels * sd * sd
+
+    def _vt(self, X):
+        sd = self.small_dim
+        return torch.matmul(torch.matmul(self.V.t(), X), self.V)[..., :sd, :sd]
+
+    def _v(self, W):
+        sd, d = self.small_dim, self.img_dim
+        full = torch.zeros(W.shape[:-2] + (d, d), dtype=W.dtype)
+        full[..., :sd, :sd] = W
+        return torch.matmul(torch.matmul(self.V, full), self.V.t())
 
     def H(self, x):
         X = x.reshape(x.shape[0], self.channels, self.img_dim, self.img_dim)
-        return (self.A @ X @ self.A.t()).reshape(x.shape[0], -1)
+        Z = self.S * self._vt(X)
+        return torch.matmul(torch.matmul(self.U, Z), self.U.t()).reshape(x.shape[0], -1)
+
+    def _adjoint(self, y, mul):
+        Y = y.reshape(y.shape[0], self.channels, self.small_dim, self.small_dim)
+        W = mul * torch.matmul(torch.matmul(self.U.t(), Y), self.U)
+        return self._v(W).reshape(y.shape[0], -1)
 
     def Ht(self, y):
-        Y = y.reshape(y.shape[0], self.channels, self.small_dim, self.small_dim)
-        return (self.A.t() @ Y @ self.A).reshape(y.shape[0], -1)
+        return self._adjoint(y, self.S)
 
     def H_pinv(self, y):
-        Y = y.reshape(y.shape[0], self.channels, self.small_dim, self.small_dim)
-        return (self.Ap @ Y @ self.Ap.t()).reshape(y.shape[0], -1)
+        return self._adjoint(y, self.Sinv)
 
 
 def random_inpaint_missing(img_dim, frac=0.92, generator=None):

@@ -77,6 +77,20 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.nhmc_gn_act_bwd(a16, a16, a16, a16, null, 0, null, 0, 1e-5, 1, a16, a16, a16, a16, 1, 1, 64, 32, 64, null) == 1   # dx_add aliases dx
     assert lib.nhmc_bias_add2(a16, a16, a16, a16, 1, 8, 6, null) == 3                                      # hw % 4
     assert lib.nhmc_ddim_mix_bwd_inpaint_px(a16, a16, 6, a16, a16, a16, a16, a16, 10, a16, a16, 0, a16, 1, 3, 100, null) == 3  # hw % 32
+    # round-3 entry points
+    assert lib.nhmc_ddim_mix_bwd_sr(a16, a16, 6, a16, a16, a16, 3, a16, a16, a16, 1, 3, 256, null) == 3                    # ratio 3
+    assert lib.nhmc_sr_vjp_tiles(3, 256, 4) == 3 * 64 and lib.nhmc_sr_vjp_tiles(3, 256, 16) == lib.nhmc_sr_tiles(3, 256, 16)
+    assert lib.nhmc_leapfrog_first_cached(a16, P(0x2000), a16, a16, a16, 512, a16, a16, 1.0, 1, 1024, a16, null) == 1     # pair_stride < n_chains * n_elem
+    assert lib.nhmc_leapfrog_first_cached(a16, P(0x2000), a16, a16, null, 1024, a16, a16, 1.0, 1, 1024, a16, null) == 1    # no sel
+    assert lib.nhmc_leapfrog_last_cached(a16, a16, a16, null, a16, a16, 1024, null, a16, 1, a16, a16, 1.0, 1, 1024, a16, null) == 1  # no loss
+    assert lib.nhmc_grad_cache_store(a16, null, a16, a16, a16, a16, 2, 1024, 1, 1, 1024, null) == 1                        # flip not in {0, 1}
+    assert lib.nhmc_grad_cache_store(a16, null, a16, a4, a16, a16, 0, 1024, 1, 1, 1024, null) == 2                         # alignment
+    assert lib.nhmc_grad_cache_flip(null, a16, 1, null) == 1
+    assert lib.nhmc_hamiltonian_cached(a16, 1, a16, null, 1, a16, 1.0, a16, null, 1, null) == 1                            # no sel
+    assert lib.nhmc_sandwich_rect(a16, a16, a16, null, a16, a16, 1, 64, 64, 48, 64, null) == 3                             # C1 % 32
+    assert lib.nhmc_data_srconv(a16, a16, a16, a16, a16, a16, null, 1, a16, a16, a16, 1, 3, 64, 32, null) == 1              # no multiplier map
+    assert lib.nhmc_data_srconv(a16, a16, a16, a16, a16, a16, a16, 1, a16, a16, a16, 1, 3, 64, 128, null) == 3             # small_dim > dim
+    assert lib.nhmc_mass_from_variance(a16, 5, null, null, a16, a16, a16, a16, 1 << 20, 1, 768, null) == 1                 # no mass table
     assert lib.nhmc_inpaint_px_tiles(3, 65536) == 3 * 64 and lib.nhmc_gn_splits(32, 128, 32, 65536) >= 1
     assert lib.nhmc_spectral_project(a16, a16, a16, a16, a16, 1, 3, 48, null) == 3                         # dim % 32
     assert lib.nhmc_spectral_project(a16, null, a16, a16, a16, 1, 3, 64, null) == 1

@@ -220,3 +220,48 @@ def test_fused_inpaint_pixel_mask_form_equals_slot_form_and_ragged_masks_fall_ba
     gx_a, ge_a = K.ddim_mix_bwd(g, xt, e, at, atn, final_clip=True)
     lb, gx_b, ge_b = ragged.fused_last_vjp(xt, e, at, atn, y2)
     assert torch.equal(gx_a, gx_b) and torch.equal(ge_a, ge_b)
+
+
+def test_mid_steps_skip_the_loss_summation_and_change_nothing_else(tiny_score):
+    """The sampler reads the per-chain loss at a trajectory's two ends only (main_sampling.py:697,717): a MID step passes
+    K.NO_LOSS, the second pass over the data term's tile partials is not launched, and gradients / decode are the same
+    bits.  (Summing inside the data-term kernel instead -- last-arriving block per chain, sc1 hand-off -- was measured at
+    129 us against 38 us for the two-pass form at 64 chains: DESIGN.md section 3.)"""
+    import nhmc.kernels as K
+    from nhmc import operators, plugin, sampler
+    dim, B = 32, 3
+    g_ = torch.Generator().manual_seed(19)
+    for deg in ('inpaint_random', 'sr4', 'deblur_aniso', 'color', 'cs4', 'sr_bicubic2'):
+        d = 64 if deg == 'sr_bicubic2' else dim
+        op = operators.build_operator(deg, 3, d, torch.device('cuda'), generator=g_)
+        xt = (torch.randn(B, 3, d, d, generator=g_) * 0.5).cuda()
+        e = torch.randn(B, 6, d, d, generator=g_).cuda()
+        y = torch.randn(B, op.M, generator=g_).cuda()
+        b = osched.betas_fp32()
+        at = osched.alpha_bar(b, torch.full((B,), 250)).cuda()
+        atn = osched.alpha_bar(b, torch.full((B,), -1)).cuda()
+        cur = K.ddim_mix_fwd(xt, e, at, atn, final_clip=True)['xt_next']
+        extra = dict(xt_next=cur) if getattr(op, 'fused_wants_decode', False) else {}
+        loss_a, gx_a, ge_a = op.fused_last_vjp(xt, e, at, atn, y, **extra)
+        loss_b, gx_b, ge_b = op.fused_last_vjp(xt, e, at, atn, y, loss_out=K.NO_LOSS, **extra)
+        assert loss_b is None and loss_a is not None
+        assert torch.equal(gx_a, gx_b) and torch.equal(ge_a[:, :3], ge_b[:, :3]), deg
+        loss_c, g_c = op.data_term(cur, y, apply_clip=False, loss_out=K.NO_LOSS)
+        assert loss_c is None
+    # through the engine: a trajectory is the same bits, and only FIRST / LAST steps (and the priming) sum a loss
+    op = operators.build_operator('inpaint_random', 3, dim, torch.device('cuda'), generator=g_)
+    algo = plugin.HMC(copy.deepcopy(tiny_score).cuda(), op, 0.1)
+    eng = sampler.LeapfrogEngine(algo.score, op, osched.betas_fp32().cuda(), SEQ, SEQ_NEXT, torch.device('cuda'))
+    x = torch.randn(B, 3, dim, dim, generator=g_).cuda()
+    p = torch.randn(B, 3, dim, dim, generator=g_).cuda()
+    y = torch.randn(B, op.M, generator=g_).cuda()
+    eps = torch.full((B,), 0.05, dtype=torch.float64, device='cuda')
+    sig = torch.full((B,), 0.9, dtype=torch.float64, device='cuda')
+    ws = K.leapfrog_ws(B, x[0].numel(), 'cuda')
+    xa, pa, xb, pb = x.clone(), p.clone(), x.clone(), p.clone()
+    _, loss_mid = eng.step(K.LF_MID, xa, xa, pa, y, eps, sig, 1.0, ws)
+    stale = loss_mid.clone()
+    _, loss_full = eng.step(K.LF_MID, xb, xb, pb, y, eps, sig, 1.0, ws, want_loss=True)
+    assert torch.equal(xa, xb) and torch.equal(pa, pb)
+    _, loss_again = eng.step(K.LF_MID, xa, xa, pa, y, eps, sig, 1.0, ws)
+    assert torch.equal(loss_again, loss_full) and stale is not None           # untouched by a MID step: still the last summed loss

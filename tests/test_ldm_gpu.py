@@ -59,6 +59,33 @@ def test_vq_kernel_takes_the_quantisers_decisions(golden):
         K.vq_nearest(torch.zeros(1, 5, 4, 4, device=dev), torch.zeros(8, 5, device=dev))
 
 
+def test_vq_kernel_on_non_finite_latents_answers_as_argmin_does_and_stays_in_bounds():
+    """a NaN / inf latent pixel (a divergent trajectory decoded through the first stage) must not send the
+    codebook gather out of bounds.  torch.argmin (the quantiser's op, taming VectorQuantizer2.forward) counts a NaN distance
+    as the minimum and returns the first one, and returns 0 for an all-inf row; the proposal then carries NaN and the
+    Metropolis test rejects it."""
+    import nhmc.kernels as K
+    dev = torch.device('cuda')
+    gen = torch.Generator().manual_seed(9)
+    for D in (3, 4):
+        z = torch.rand(1, D, 16, 16, generator=gen) * 2 - 1
+        cb = torch.randn(8192, D, generator=gen) * 0.5
+        z[0, 0, 0, 0] = float('nan')                     # every distance NaN -> index 0
+        z[0, 1, 0, 1] = float('inf')                     # NaN where the inner product is +inf, +inf elsewhere -> first NaN
+        z[0, 2, 0, 2] = float('-inf')
+        z[0, :, 0, 3] = float('inf')
+        z[0, :, 0, 4] = 3.0e38                           # finite, but the squared norm overflows: distances +inf or NaN
+        want_q, want_i = ldm_ref.vq_straight_through(z, cb)
+        got_q, got_i = K.vq_nearest(z.to(dev), cb.to(dev))
+        torch.cuda.synchronize()
+        assert int(got_i.min()) >= 0 and int(got_i.max()) < 8192
+        assert torch.equal(got_i.cpu().long(), want_i), (got_i.cpu().long() != want_i).nonzero()[:5]
+        assert int(want_i[0, 0, 0]) == 0                 # all NaN: argmin answers 0
+        assert torch.equal(torch.isnan(got_q.cpu()), torch.isnan(want_q))
+        fin = torch.isfinite(want_q)
+        assert torch.equal(got_q.cpu()[fin], want_q[fin])
+
+
 def test_networks_on_the_gpu_match_the_reference_classes(golden):
     g = golden('g12_ldm_16.npz')
     dev = torch.device('cuda')

@@ -59,13 +59,58 @@ def test_mass_from_variance_rank_transform():
     m2 = torch.rand(3, 3, 16, 16, generator=g_)
     inv, std = torch.ones(3, 3, 16, 16, device='cuda'), torch.ones(3, 3, 16, 16, device='cuda')
     flags = torch.tensor([1, 0, 1], dtype=torch.int32).cuda()
-    K.mass_from_variance(m2.cuda(), 5, flags, inv, std)
+    m2[0].view(-1)[100:140] = 0.25                                      # ties: broken by index, as torch.sort(stable=True)
+    m2[2].view(-1)[::7] = 0.0
+    from nhmc.schedule import mass_tables
+    K.mass_from_variance(m2.cuda(), 5, flags, inv, std, mass_tables(m2[0].numel(), 'cuda'))
     for c in range(3):
         M_ref, std_ref, inv_ref = mass_ref.mass_from_variance(m2[c], 5, stable=True)
         if c == 1:
             assert float((inv[c] - 1).abs().max()) == 0 and float((std[c] - 1).abs().max()) == 0
-        else:
-            assert rel(inv[c].reshape(-1), inv_ref) < 1e-6 and rel(std[c].reshape(-1), std_ref) < 1e-6
+        else:                                                          # the same host tables on both sides: the same bits
+            assert torch.equal(inv[c].reshape(-1).cpu(), inv_ref) and torch.equal(std[c].reshape(-1).cpu(), std_ref)
+
+
+def test_reference_diagonal_mass_run_on_the_gpu(golden, tiny_score):
+    """G11b = the reference's `hmc_test_conditioning` (main_sampling.py:776-894) run with ties of the rank transform broken
+    by index (oracle/gen_golden_mass.py stable; the oracle reproduces it bit for bit, tests/test_mass_cpu.py), replayed on
+    the GPU on the run's own tape: every accept decision outside the ambiguity band, the energy differences, and the 35
+    returned images within north_star's 1e-4.  The mass tables (sqrt(M_r), 1/M_r by rank) are the recorded ones of the
+    host the reference ran on: they are that host's libm, not kernel arithmetic."""
+    from nhmc import operators, plugin, sampler
+    from oracle.tiny_score import F64Score
+    T = torch.from_numpy
+    g = golden('g11b_hmc_mass_stable_16.npz')
+    dim, dev = 16, torch.device('cuda')
+    n = len(g['u'])
+    torch.manual_seed(int(g['seed']))
+    P, U = [], []
+    for _ in range(n):
+        P.append(torch.randn(1, 3, dim, dim))
+        U.append(float(torch.rand(1)))
+    assert np.array_equal(np.array(U), g['u']) and np.array_equal(P[0].numpy(), g['p0']) and np.array_equal(P[-1].numpy(), g['p_last'])
+    prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
+    ref_acc = g['u'] < prob
+    ambiguous = np.abs(g['u'] - prob) < 0.02
+    u_play = np.where(ambiguous, np.where(ref_acc, 0.0, 1.0), g['u']).astype(np.float32)
+    op = operators.Inpainting(3, dim, T(g['missing']), dev)
+    algo = plugin.HMC(F64Score(tiny_score).to(dev), op, float(g['sigma_0']))
+    opt = types.SimpleNamespace(tau=float(g['tau']), epsilon=float(g['epsilon']), sigma_0=float(g['sigma_0']))
+    M = T(g['M_by_rank'])
+    res = sampler.hmc_mass_chains(T(g['x']).to(dev), osched.betas_fp32().to(dev), SEQ, SEQ_NEXT, algo, opt, T(g['y_0']).to(dev), op,
+                                  T(g['x_orig']).to(dev), noise=sampler.TapeNoise(lambda it: P[it], lambda it: torch.tensor([u_play[it]])),
+                                  collect_trace=True, max_iters=n, mass_tables=(T(g['std_by_rank']), 1.0 / M))
+    assert res.iters == n
+    got_acc = np.array([bool(r['accept'][0]) for r in res.trace])
+    got_dH = np.array([float(r['dH'][0]) for r in res.trace])
+    assert np.array_equal(got_acc, ref_acc), np.nonzero(got_acc != ref_acc)[0][:5]
+    small = np.abs(g['neg_dH']) < 50
+    worst = float(np.max(np.abs(got_dH[small] + g['neg_dH'][small])))
+    err = rel(res.samples[0], T(g['out']))
+    print(f'diagonal-mass run: {n} trajectories, {int(ambiguous.sum())} inside the accept band, max |dH - dH_ref| {worst:.4f}, '
+          f'returned images rel err {err:.2e} ({int(g["sorts"])} rank transforms, {int(g["tied_elements"])} tied elements)')
+    assert worst < 0.05
+    assert res.samples.shape == (1, 35, 3, dim, dim) and err < 1e-4
 
 
 def test_mass_loop_takes_the_oracles_decisions(tiny_score):

@@ -131,3 +131,38 @@ def test_projected_form_on_the_reference_run(golden, tiny_score):
     worst = np.max(np.abs(got_dH[small] + g['neg_dH'][:N][small]))
     print(f'projected form, first {N} trajectories of the reference run: max |dH - dH_ref| = {worst:.4f}')
     assert worst < 0.05
+
+
+def test_projected_form_under_graph_replay_uses_each_chunks_own_observation(tiny_score):
+    """with --graph and the projected form together, the captured graph must contain the projection launch.
+    The engine keys its graphs by shape and refills the static observation buffer per chunk; had the capture hit the
+    projection cache (filled by the warm-up calls), chunks after the first would be evaluated against the first
+    chunk's y^.  Two chunks with different observations, graph on vs off."""
+    from nhmc import operators, plugin, sampler
+    from oracle import schedule as osched
+
+    class PointwiseScore(torch.nn.Module):                             # capturable: no host tensor is built in forward
+        def forward(self, x, t):
+            a = (t / 1000.0).view(-1, 1, 1, 1)
+            e = torch.tanh(x * 0.7) * (0.5 + a)
+            return torch.cat([e, torch.zeros_like(e)], dim=1)
+
+    dev = torch.device('cuda')
+    dim, B = 32, 4
+    g_ = torch.Generator().manual_seed(77)
+    op = operators.build_operator('deblur_aniso', 3, dim, dev, spectral_projected=True)
+    assert op.projected
+    algo = plugin.HMC(PointwiseScore().to(dev), op, 0.1)
+    x = torch.randn(B, 3, dim, dim, generator=g_).to(dev)
+    y = (torch.randn(B, op.M, generator=g_)).to(dev)                  # every chain its own observation
+    outs = []
+    for graph in (False, True, True):                                  # the second graphed call is a pure replay
+        eng = sampler.LeapfrogEngine(algo.score, op, osched.betas_fp32().to(dev), [250, 500, 750], [-1, 250, 500], dev, chunk=2) \
+            if graph is False or len(outs) == 1 else eng
+        xt, loss, ga, gb = eng.decode_and_grad(x, y, graph=graph)
+        outs.append((xt.clone(), loss.clone(), ga.clone(), gb.clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            err = float((a.double() - b.double()).abs().max() / a.double().abs().max())
+            assert err < 1e-5, err                                     # same kernels; a wrong observation moves the loss by O(1)
+    assert float((outs[0][1][:2] - outs[0][1][2:]).abs().min()) > 1e-3 * float(outs[0][1].abs().max())   # the chunks do differ

@@ -17,9 +17,11 @@ def rel(a, b):
 def test_g10_srconv(golden, dim):
     g = golden(f'g10_srconv_{dim}.npz')
     op = oops.SeparableStridedRef(T(g['kernel']), 3, dim, int(g['factor']))
-    assert rel(op.H(T(g['x'])).numpy(), g['Hx']) < 5e-6
-    assert rel(op.Ht(T(g['y'])).numpy(), g['Hty']) < 5e-6
-    assert rel(op.H_pinv(T(g['y'])).numpy(), g['Hpinvy']) < 2e-4
+    # the reference's stage order: bit-identical on the torch build that wrote G10; 1e-6 leaves room for another
+    # host's BLAS blocking (round 2's collapsed form needed 2e-4 for H^+)
+    assert rel(op.H(T(g['x'])).numpy(), g['Hx']) < 1e-6
+    assert rel(op.Ht(T(g['y'])).numpy(), g['Hty']) < 1e-6
+    assert rel(op.H_pinv(T(g['y'])).numpy(), g['Hpinvy']) < 1e-6
 
 
 def test_product_bicubic_taps_match_reference_kernel(golden):

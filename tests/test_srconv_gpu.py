@@ -20,7 +20,7 @@ def test_srconv_against_reference_outputs(golden, dim):
     op = operators.SRConv(T(g['kernel']), 3, dim, 'cuda', stride=int(g['factor']))
     assert rel(op.H(T(g['x']).cuda()), T(g['Hx'])) < 2e-5
     assert rel(op.Ht(T(g['y']).cuda()), T(g['Hty'])) < 2e-5
-    assert rel(op.H_pinv(T(g['y']).cuda()), T(g['Hpinvy'])) < 5e-4
+    assert rel(op.H_pinv(T(g['y']).cuda()), T(g['Hpinvy'])) < 2e-5
 
 
 @pytest.mark.parametrize('dim,factor,B', [(64, 2, 2), (128, 4, 3), (256, 4, 2)])
