@@ -229,22 +229,26 @@ int nhmc_color_Ht(const float* y, const float* w, int pinv, float* x, int n_chai
 
 /* Walsh-Hadamard compressive sensing (Hfuncs.py:611-651): y[k*C + c] = (FWHT(x_c) / d)[perm[k]], k < d*d/ratio;
  * H^T = H^+.  kslot: int32[d*d], position -> k or -1 (inverse of perm restricted to the kept rows).  m = row length
- * of y (= C*d*d/ratio).  dim: power of two, 16..256.  tmp: float[n_chains*C*d*d] (x2 for the data term).
- * loss partials: nhmc_cs_tiles(channels, dim) per chain. */
+ * of y (= C*d*d/ratio).  dim: power of two, 16..256.  tmp: float[n_chains*C*d*d].
+ * loss partials: nhmc_cs_tiles(channels, dim) per chain.
+ * The data term takes the observation in SPECTRUM layout: y_spec = float[n_chains][C][d*d] with
+ * y_spec[chain][c][perm[k]] = y[chain][k*C + c] and NaN at the positions that are not observed -- constant over a run,
+ * scattered once by the host -- so that the residual is a coalesced read instead of a gather per element, and at d = 256
+ * the forward column pass, the residual and the adjoint's column pass run as ONE kernel on a register-resident panel
+ * (three passes over the image instead of four).  tmp for the data term: float[n_chains*C*d*d] at d = 256, twice that
+ * otherwise. */
 int nhmc_cs_tiles(int channels, int dim);
 int nhmc_cs_H(const float* x, const int32_t* kslot, float* y, float* tmp, int n_chains, int channels, int dim,
               int64_t m, nhmc_stream_t stream);
 int nhmc_cs_Ht(const float* y, const int32_t* kslot, float* x, float* tmp, int n_chains, int channels, int dim,
                int64_t m, nhmc_stream_t stream);
-int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslot, int apply_clip, float* g_xt,
-                 double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
-                 nhmc_stream_t stream);
-/* nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last column
+int nhmc_data_cs(const float* xt, const float* y_spec, int apply_clip, float* g_xt, double* loss_ws, float* tmp,
+                 int n_chains, int channels, int dim, nhmc_stream_t stream);
+/* nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last row
  * pass: writes g_xt and channels [0, channels) of g_e (the caller keeps the sigma-channels zero). */
-int nhmc_data_cs_vjp(const float* xt_next, const float* y, const int32_t* kslot, const float* xt, const float* e,
-                     int e_channels, const float* at, const float* at_next, float* g_xt, float* g_e,
-                     double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
-                     nhmc_stream_t stream);
+int nhmc_data_cs_vjp(const float* xt_next, const float* y_spec, const float* xt, const float* e, int e_channels,
+                     const float* at, const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
+                     int n_chains, int channels, int dim, nhmc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * a15  Spectral (anisotropic-blur) operator   Hfuncs.py:448-523
@@ -257,19 +261,27 @@ int nhmc_data_cs_vjp(const float* xt_next, const float* y, const int32_t* kslot,
  * nhmc_data_spectral    : r = y - H clip(xt); loss partials (nhmc_spectral_tiles per chain);
  *                         g_xt = -2 H^T r (masked).  factors: packed [8][d][d] =
  *                         U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T.  tmp: float[2*n_chains*C*d*d] scratch.
+ *                         The forward multiplies by the left factor first (Hfuncs.py:493-509), the adjoint by the
+ *                         RIGHT factor first -- the order autograd differentiates those matmuls in at
+ *                         main_sampling.py:695,711 -- and every product is an exact k-ascending FMA chain, as
+ *                         torch's CPU sgemm is: the data term is the reference's bits.  The right-first order runs on
+ *                         transposed operands, hence two constant inputs in transposed form:
+ *                         yT = the observation with every channel plane transposed ([n_chains][C][d][d]),
+ *                         DmapT = Dmap with every channel plane transposed.
  * ---------------------------------------------------------------------------------- */
 int nhmc_spectral_apply(const float* x, const float* L, const float* R, const float* Dmap,
                         const float* LoT, const float* RoT, float* out, float* tmp,
                         int n_chains, int channels, int dim, nhmc_stream_t stream);
 int nhmc_spectral_tiles(int channels, int dim);
-int nhmc_data_spectral(const float* xt, const float* y, const float* factors, const float* Dmap,
-                       int apply_clip, float* g_xt, double* loss_ws, float* tmp,
+int nhmc_data_spectral(const float* xt, const float* yT, const float* factors, const float* Dmap,
+                       const float* DmapT, int apply_clip, float* g_xt, double* loss_ws, float* tmp,
                        int n_chains, int channels, int dim, nhmc_stream_t stream);
 /* a11 + a12/a15 fused: data term on xt_next (the clipped decode of the LAST DDIM step, as nhmc_ddim_mix_fwd wrote it)
  * with the step's VJP applied in the last product's epilogue: writes g_xt and channels [0, channels) of g_e (the caller
  * keeps its sigma-channels zero).  Replaces nhmc_data_spectral(apply_clip = 0) + nhmc_ddim_mix_bwd(final_clip = 1). */
-int nhmc_data_spectral_vjp(const float* xt_next, const float* y, const float* factors, const float* Dmap,
-                           const float* xt, const float* e, int e_channels, const float* at, const float* at_next,
+int nhmc_data_spectral_vjp(const float* xt_next, const float* yT, const float* factors, const float* Dmap,
+                           const float* DmapT, const float* xt, const float* e, int e_channels, const float* at,
+                           const float* at_next,
                            float* g_xt, float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim,
                            nhmc_stream_t stream);
 
@@ -299,7 +311,9 @@ int nhmc_data_spectral_proj_vjp(const float* xt_next, const float* y_proj, const
  *   S1 [K1][C1], S2 [R1][C2], mul [C1][C2] (nullable: no multiplication), out [C1][C2] (all dims % 32 == 0);
  *   tmp: float[n_img*R1*C1].   V1^T X V1: in = X, S1 = S2 = V1, mul = S;   U Z U^T: in = Z, S1 = S2 = U^T.
  * nhmc_data_srconv: r = y - H(clip(xt)), loss partials (nhmc_srconv_tiles per chain), g = -2 H^T r (masked): eight
- *   products.  V1T = V1^T as stored [sd][d], UT = U^T [sd][sd];  tmp: float[n_chains*C*(d*sd + 3*sd*sd)]. */
+ *   products, the adjoint right factor first as in nhmc_data_spectral (autograd's order), so `y` is the observation
+ *   with every channel plane TRANSPOSED ([n_chains][C][sd][sd]).  V1T = V1^T as stored [sd][d], UT = U^T [sd][sd];
+ *   tmp: float[n_chains*C*(d*sd + 3*sd*sd)]. */
 int nhmc_sandwich_rect(const float* in, const float* S1, const float* S2, const float* mul, float* out, float* tmp,
                        int n_img, int K1, int R1, int C1, int C2, nhmc_stream_t stream);
 int nhmc_srconv_tiles(int channels, int small_dim);

@@ -51,12 +51,12 @@ SIGNATURES = {
     'nhmc_cs_tiles': (I, [I, I]),
     'nhmc_cs_H': (I, [P, P, P, P, I, I, I, I64, P]),
     'nhmc_cs_Ht': (I, [P, P, P, P, I, I, I, I64, P]),
-    'nhmc_data_cs': (I, [P, P, P, I, P, P, P, I, I, I, I64, P]),
-    'nhmc_data_cs_vjp': (I, [P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I64, P]),
+    'nhmc_data_cs': (I, [P, P, I, P, P, P, I, I, I, P]),
+    'nhmc_data_cs_vjp': (I, [P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
     'nhmc_spectral_apply': (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     'nhmc_spectral_tiles': (I, [I, I]),
-    'nhmc_data_spectral': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
-    'nhmc_data_spectral_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
+    'nhmc_data_spectral': (I, [P, P, P, P, P, I, P, P, P, I, I, I, P]),
+    'nhmc_data_spectral_vjp': (I, [P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),
     'nhmc_spectral_project': (I, [P, P, P, P, P, I, I, I, P]),
     'nhmc_data_spectral_proj': (I, [P, P, P, P, I, P, P, P, I, I, I, P]),
     'nhmc_data_spectral_proj_vjp': (I, [P, P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, P]),

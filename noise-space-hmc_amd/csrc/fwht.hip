@@ -214,9 +214,9 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols(const float* __restric
       const int k = kslot[q];
       if (k >= 0) y_out[chain * m + (int64_t)k * channels + c] = v;
     } else if (EPI == EPI_RESID) {
-      const int k = kslot[q];
+      const float ys = y[off];                                      // observation in spectrum layout, NaN = not observed
       float r = 0.0f;
-      if (k >= 0) { r = y[chain * m + (int64_t)k * channels + c] - v; acc += r * r; }
+      if (ys == ys) { r = ys - v; acc += r * r; }
       out[off] = r;                                                 // zero-filled spectrum of the residual
     } else if (EPI == EPI_VJP) {
       const VjpCoef k = vjp_coef(vj, chain);
@@ -341,13 +341,12 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __rest
       if (ks.z >= 0) y_out[chain * m + (int64_t)ks.z * channels + c] = val.z;
       if (ks.w >= 0) y_out[chain * m + (int64_t)ks.w * channels + c] = val.w;
     } else if (EPI == EPI_RESID) {
-      const int4 ks = *reinterpret_cast<const int4*>(&kslot[q]);
-      const int kk[4] = {ks.x, ks.y, ks.z, ks.w};
+      const nhmc_v4f ys = *reinterpret_cast<const nhmc_v4f*>(&y[off]);   // spectrum layout, NaN = not observed
       nhmc_v4f r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float re = 0.0f;
-        if (kk[e] >= 0) { re = y[chain * m + (int64_t)kk[e] * channels + c] - val[e]; acc += re * re; }
+        if (ys[e] == ys[e]) { re = ys[e] - val[e]; acc += re * re; }
         r[e] = re;
       }
       *reinterpret_cast<nhmc_v4f*>(&out[off]) = r;
@@ -381,6 +380,70 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256(const float* __rest
     nhmc_block_sum<1>(sacc, red);
     if (threadIdx.x == 0) loss_ws[plane * gridDim.x + blockIdx.x] = sacc[0];
   }
+}
+
+// ---- d = 256: forward columns + residual + adjoint columns in ONE pass -------------------------------------------------
+// The forward column pass ends with a thread owning the 16 STRIDED rows rg + 16 k of its column group, and the descending
+// (adjoint) column pass starts in exactly that ownership: so the residual spectrum never has to leave the registers
+// between them.  ascending h = 1..8 (consecutive rows) -> LDS exchange -> h = 16..128 (strided rows) -> * 1/256,
+// r = y_spec - v (0 where not observed), loss partial -> descending h = 128..16 (the same strided rows) -> LDS exchange ->
+// h = 8..1 (consecutive rows) -> raw store (the descending row pass that follows scales and applies the gradient epilogue).
+// One read + one write of the panel instead of two of each, one launch instead of two; every butterfly is the one the
+// two-kernel form computes, in the same order: the same bits.  In place is allowed (a block owns its panel).
+__global__ __launch_bounds__(NHMC_BLOCK) void k_fwht_cols256_resid_adj(const float* __restrict__ in, float* __restrict__ out,
+                                                                       const float* __restrict__ y_spec,
+                                                                       double* __restrict__ loss_ws) {
+  constexpr int D = 256, PC = 64;
+  __shared__ nhmc_v4f tile[D * PC / 4];
+  const int64_t plane = blockIdx.y;
+  const int c0 = blockIdx.x * PC;
+  const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
+  const int64_t pbase = plane * (int64_t)D * D + c0 + cg * 4;
+  nhmc_v4f v[16], ys[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const nhmc_v4f*>(&in[pbase + (int64_t)(rg * 16 + k) * D]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) ys[k] = *reinterpret_cast<const nhmc_v4f*>(&y_spec[pbase + (int64_t)(rg + 16 * k) * D]);
+#define NHMC_BFLY(H)                                                                     \
+  _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                       \
+    if ((k & (H)) == 0) { const nhmc_v4f a = v[k], b = v[k + (H)]; v[k] = a + b; v[k + (H)] = a - b; } \
+  }
+  NHMC_BFLY(1) NHMC_BFLY(2) NHMC_BFLY(4) NHMC_BFLY(8)                  // row strides 1, 2, 4, 8
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tile[(rg * 16 + k) * (PC / 4) + cg] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = tile[(rg + 16 * k) * (PC / 4) + cg];
+  NHMC_BFLY(1) NHMC_BFLY(2) NHMC_BFLY(4) NHMC_BFLY(8)                  // row strides 16, 32, 64, 128
+  const float scale = 1.0f / 256.0f;
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {                                       // ascending k, as the two-kernel form's epilogue loop
+    const nhmc_v4f val = v[k] * scale;
+    nhmc_v4f r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float re = 0.0f;
+      if (ys[k][e] == ys[k][e]) { re = ys[k][e] - val[e]; acc += re * re; }
+      r[e] = re;
+    }
+    v[k] = r;
+  }
+  NHMC_BFLY(8) NHMC_BFLY(4) NHMC_BFLY(2) NHMC_BFLY(1)                  // descending: row strides 128, 64, 32, 16
+  __syncthreads();                                                     // every thread has read its strided rows of the first exchange
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tile[(rg + 16 * k) * (PC / 4) + cg] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = tile[(rg * 16 + k) * (PC / 4) + cg];
+  NHMC_BFLY(8) NHMC_BFLY(4) NHMC_BFLY(2) NHMC_BFLY(1)                  // row strides 8, 4, 2, 1
+#undef NHMC_BFLY
+#pragma unroll
+  for (int k = 0; k < 16; ++k) *reinterpret_cast<nhmc_v4f*>(&out[pbase + (int64_t)(rg * 16 + k) * D]) = v[k];
+  __shared__ double red[4];
+  double sacc[1] = {(double)acc};
+  nhmc_block_sum<1>(sacc, red);
+  if (threadIdx.x == 0) loss_ws[plane * gridDim.x + blockIdx.x] = sacc[0];
 }
 
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -447,44 +510,56 @@ extern "C" int nhmc_cs_Ht(const float* y, const int32_t* kslot, float* x, float*
   return cols<EPI_STORE>(tmp, x, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, m, 0, nhmc_s(stream));
 }
 
-// loss partials (nhmc_cs_tiles per chain) and g_xt = -2 H^T (y - H clip(xt)) (x) mask.  tmp: 2 images worth.
-extern "C" int nhmc_data_cs(const float* xt, const float* y, const int32_t* kslot, int apply_clip, float* g_xt,
-                            double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
-                            nhmc_stream_t stream) {
-  if (!xt || !y || !kslot || !g_xt || !loss_ws || !tmp || m <= 0) return NHMC_ERR_ARG;
+namespace {
+// forward rows were written to A; residual + both column passes; leaves the raw adjoint spectrum (column stages done) in A
+int cs_columns(float* A, float* B, const float* y_spec, double* loss_ws, int n_chains, int channels, int dim, hipStream_t st) {
+  if (dim == 256) {
+    NHMC_LAUNCH(k_fwht_cols256_resid_adj, dim3(4u, (unsigned)(n_chains * channels)), dim3(NHMC_BLOCK), 0, st, A, A, y_spec, loss_ws);
+    return nhmc_launch_status();
+  }
+  int rc;
+  if ((rc = cols<EPI_RESID>(A, B, y_spec, nullptr, nullptr, nullptr, loss_ws, n_chains, channels, dim, 0, 0, st))) return rc;
+  return cols<EPI_RAW, true>(B, A, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, 0, 0, st);
+}
+}  // namespace
+
+// loss partials (nhmc_cs_tiles per chain) and g_xt = -2 H^T (y - H clip(xt)) (x) mask.
+// y_spec: the observation in SPECTRUM layout, float[n_chains][C][dim*dim], y_spec[chain][c][perm[k]] = y[chain][k*C + c]
+// and NaN at the positions that are not observed (constant over a run; the host scatters it once).
+// tmp: float[n_chains*C*dim*dim] for dim = 256 (the column passes run fused and in place), twice that otherwise.
+extern "C" int nhmc_data_cs(const float* xt, const float* y_spec, int apply_clip, float* g_xt, double* loss_ws, float* tmp,
+                            int n_chains, int channels, int dim, nhmc_stream_t stream) {
+  if (!xt || !y_spec || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
   if (bad(n_chains, channels, dim) || dim > 256) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y_spec) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(tmp)) return NHMC_ERR_ALIGN;
   hipStream_t st = nhmc_s(stream);
   float* A = tmp;
   float* B = tmp + (int64_t)n_chains * channels * dim * dim;
   int rc;
-  if (apply_clip) { if ((rc = rows<PRO_CLIP>(xt, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc; }
-  else            { if ((rc = rows<PRO_NONE>(xt, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc; }
-  if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
+  if (apply_clip) { if ((rc = rows<PRO_CLIP>(xt, nullptr, nullptr, A, n_chains, channels, dim, 0, st))) return rc; }
+  else            { if ((rc = rows<PRO_NONE>(xt, nullptr, nullptr, A, n_chains, channels, dim, 0, st))) return rc; }
   // adjoint in autograd's order: column stages descending, then row stages descending with the gradient epilogue
-  if ((rc = cols<EPI_RAW, true>(B, A, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, m, 0, st))) return rc;
-  return rows<PRO_NONE, true, EPI_GRAD>(A, nullptr, nullptr, g_xt, n_chains, channels, dim, m, st, xt, apply_clip);
+  if ((rc = cs_columns(A, B, y_spec, loss_ws, n_chains, channels, dim, st))) return rc;
+  return rows<PRO_NONE, true, EPI_GRAD>(A, nullptr, nullptr, g_xt, n_chains, channels, dim, 0, st, xt, apply_clip);
 }
 
-// nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last column
+// nhmc_data_cs on xt_next (the clipped decode of the LAST DDIM step) with that step's VJP applied in the last row
 // pass: writes g_xt and channels [0, channels) of g_e.
-extern "C" int nhmc_data_cs_vjp(const float* xt_next, const float* y, const int32_t* kslot, const float* xt,
-                                const float* e, int e_channels, const float* at, const float* at_next, float* g_xt,
-                                float* g_e, double* loss_ws, float* tmp, int n_chains, int channels, int dim, int64_t m,
-                                nhmc_stream_t stream) {
-  if (!xt_next || !y || !kslot || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp || m <= 0)
-    return NHMC_ERR_ARG;
+extern "C" int nhmc_data_cs_vjp(const float* xt_next, const float* y_spec, const float* xt, const float* e, int e_channels,
+                                const float* at, const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
+                                int n_chains, int channels, int dim, nhmc_stream_t stream) {
+  if (!xt_next || !y_spec || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp) return NHMC_ERR_ARG;
   if (bad(n_chains, channels, dim) || dim > 256 || (e_channels != channels && e_channels != 2 * channels))
     return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) ||
-      !nhmc_aligned16(g_e) || !nhmc_aligned16(tmp) || !nhmc_aligned16(kslot))
+      !nhmc_aligned16(g_e) || !nhmc_aligned16(tmp) || !nhmc_aligned16(y_spec))
     return NHMC_ERR_ALIGN;
   hipStream_t st = nhmc_s(stream);
   float* A = tmp;
   float* B = tmp + (int64_t)n_chains * channels * dim * dim;
   int rc;
-  if ((rc = rows<PRO_NONE>(xt_next, nullptr, nullptr, A, n_chains, channels, dim, m, st))) return rc;
-  if ((rc = cols<EPI_RESID>(A, B, y, nullptr, kslot, nullptr, loss_ws, n_chains, channels, dim, m, 0, st))) return rc;
-  if ((rc = cols<EPI_RAW, true>(B, A, nullptr, nullptr, nullptr, nullptr, nullptr, n_chains, channels, dim, m, 0, st))) return rc;
+  if ((rc = rows<PRO_NONE>(xt_next, nullptr, nullptr, A, n_chains, channels, dim, 0, st))) return rc;
+  if ((rc = cs_columns(A, B, y_spec, loss_ws, n_chains, channels, dim, st))) return rc;
   const VjpArgs vj{e, g_e, at, at_next, e_channels};
-  return rows<PRO_NONE, true, EPI_VJP>(A, nullptr, nullptr, g_xt, n_chains, channels, dim, m, st, xt, 0, vj);
+  return rows<PRO_NONE, true, EPI_VJP>(A, nullptr, nullptr, g_xt, n_chains, channels, dim, 0, st, xt, 0, vj);
 }

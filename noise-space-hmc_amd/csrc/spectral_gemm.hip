@@ -34,7 +34,14 @@ enum { EPI_NONE = 0, EPI_MULD = 1, EPI_RESID = 2, EPI_GRAD = 3, EPI_VJP = 4, EPI
 struct VjpArgs { const float* e; float* g_e; const float* at; const float* at_next; int e_channels; };
 constexpr int BK = 32;
 
-template <int T, int NW, int EPI, bool PRECLIP>
+// TOUT: the product is STORED TRANSPOSED, OUT_T[c][r] = sum_k IN[k][r] S[k][c], and the epilogue (Dmap / aux / e / g_e
+// reads, the store) works in the coordinates of that transposed matrix.  It is what lets a chain of this one kernel form
+// multiply from the RIGHT first: autograd differentiates U (D o (V^T x V)) U^T as  r U, then U^T (.), then (.) V^T, then
+// V (.) -- right factor first at both sandwiches -- and in the space of transposed operands OUT = IN^T S is a right
+// multiplication (IN = M^T gives M S).  So the residual is written transposed by the forward's last product and the
+// gradient is transposed back by the adjoint's last product, both inside their epilogues; the accumulator slab is
+// XOR-swizzled in LDS so that the column-wise reads of the transposing epilogue stay conflict-free.
+template <int T, int NW, int EPI, bool PRECLIP, bool TOUT = false>
 __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1) void k_sgemm(
     const float* __restrict__ IN, const float* __restrict__ S, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int K, int R, int C,
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
   const float* __restrict__ dm_img = (EPI == EPI_MULD || EPI == EPI_SRES) ? Dmap + (int64_t)c * R * C : nullptr;
   const float* __restrict__ aux_img = aux ? aux + (int64_t)img * R * C : nullptr;
   float lsum = 0.0f;
+  constexpr int SR = T / NW;                            // rows of one accumulator slab
   // EPI_VJP: aux = the DDIM step's input xt; e / g_e are [chain][e_channels][R][C]
   const float* __restrict__ e_img = nullptr;
   float* __restrict__ ge_img = nullptr;
@@ -132,15 +140,27 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 #pragma unroll
         for (int fb = 0; fb < FR; ++fb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            L[(fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * T + (wj * FR + fb) * 32 + lr] = acc[fa][fb][r];
+          for (int r = 0; r < 16; ++r) {
+            const int row = fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = (wj * FR + fb) * 32 + lr;
+            L[row * T + (TOUT ? (col ^ ((row >> 2) & 31)) : col)] = acc[fa][fb][r];
+          }
     }
     __syncthreads();
 #pragma unroll
     for (int v = 0; v < SLAB_V; ++v) {
-      const int idx = tid + v * NT, row = idx / (T / 4), c4i = idx % (T / 4);
-      const int off = (tr + h * (T / NW) + row) * C + tc + c4i * 4;
-      nhmc_v4f q = *reinterpret_cast<const nhmc_v4f*>(&L[row * T + c4i * 4]);
+      const int idx = tid + v * NT;
+      int off;
+      nhmc_v4f q;
+      if (TOUT) {                                       // 4 consecutive ROWS of one column = 4 consecutive floats of OUT_T
+        const int r4 = idx % (SR / 4), col = idx / (SR / 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = L[(r4 * 4 + j) * T + (col ^ (r4 & 31))];
+        off = (tc + col) * R + tr + h * SR + r4 * 4;
+      } else {
+        const int row = idx / (T / 4), c4i = idx % (T / 4);
+        off = (tr + h * SR + row) * C + tc + c4i * 4;
+        q = *reinterpret_cast<const nhmc_v4f*>(&L[row * T + c4i * 4]);
+      }
       if (EPI == EPI_MULD) {
         const nhmc_v4f d = *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
         q = q * d;
@@ -218,7 +238,8 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 // So the pair form does not beat the chain on time -- each block still serialises ~16 us of slab staging, barriers and
 // the 64 KB epilogue against 27 us of MFMA work, and one block fits a CU -- but it halves the launches and keeps
 // half of the intermediates (8T of 16T per chain) out of HBM.
-template <int EPI, bool PRECLIP, int NW>
+// TOUT: as in k_sgemm -- the pair's result is stored transposed (and its epilogue runs in the transposed coordinates).
+template <int EPI, bool PRECLIP, int NW, bool TOUT = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
     const float* __restrict__ IN, const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int channels, VjpArgs vj) {
@@ -332,8 +353,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        slab[(fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + (wave * F + f) * 32 + lr] = acc[f][fa][r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = (wave * F + f) * 32 + lr;
+        slab[row * D + (TOUT ? (col ^ (row >> 2)) : col)] = acc[f][fa][r];       // 64 rows: row >> 2 < 16, stays in the 32-group
+      }
   __syncthreads();
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * D * D;
@@ -353,9 +376,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
   float lsum = 0.0f;
 #pragma unroll 4
   for (int v = 0; v < SL * D / 4 / NT; ++v) {
-    const int idx = tid + v * NT, row = idx / (D / 4), c4i = idx % (D / 4);
-    const int off = (q * SL + row) * D + c4i * 4;
-    nhmc_v4f o = *reinterpret_cast<const nhmc_v4f*>(&slab[row * D + c4i * 4]);
+    const int idx = tid + v * NT;
+    int off;
+    nhmc_v4f o;
+    if (TOUT) {                                             // 4 consecutive rows of one column = 4 consecutive floats of OUT_T
+      const int r4 = idx % (SL / 4), col = idx / (SL / 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = slab[(r4 * 4 + j) * D + (col ^ r4)];
+      off = col * D + q * SL + r4 * 4;
+    } else {
+      const int row = idx / (D / 4), c4i = idx % (D / 4);
+      off = (q * SL + row) * D + c4i * 4;
+      o = *reinterpret_cast<const nhmc_v4f*>(&slab[row * D + c4i * 4]);
+    }
     if (EPI == EPI_MULD) o = o * *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
     if (EPI == EPI_RESID) {
       o = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]) - o;                   // r = y - H x
@@ -407,52 +440,50 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
 
 constexpr int PAIR_LDS_BYTES = 256 * 64 * 4;                // one 64 KB slab region (S1 slab, then T1 slab, then output staging)
 
-template <int EPI, bool PRECLIP, int NW>
+template <int EPI, bool PRECLIP, int NW, bool TOUT>
 int pair256_nw(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
                int n_img, int channels, hipStream_t st, VjpArgs vj) {
   static bool attr_set[64] = {};                             // raise the dynamic-LDS limit of this instantiation once per device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair256<EPI, PRECLIP, NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair256<EPI, PRECLIP, NW, TOUT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES) != hipSuccess)
       return NHMC_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  NHMC_LAUNCH((k_pair256<EPI, PRECLIP, NW>), dim3((unsigned)(4 * n_img)), dim3(64 * NW), PAIR_LDS_BYTES, st, IN, S1, S2, OUT,
-              Dmap, aux, ws, channels, vj);
+  NHMC_LAUNCH((k_pair256<EPI, PRECLIP, NW, TOUT>), dim3((unsigned)(4 * n_img)), dim3(64 * NW), PAIR_LDS_BYTES, st, IN, S1, S2,
+              OUT, Dmap, aux, ws, channels, vj);
   return nhmc_launch_status();
 }
 
-template <int EPI, bool PRECLIP>
+template <int EPI, bool PRECLIP, bool TOUT = false>
 int pair256(const float* IN, const float* S1, const float* S2, float* OUT, const float* Dmap, const float* aux, double* ws,
             int n_img, int channels, hipStream_t st, VjpArgs vj = VjpArgs{}) {
-  const char* v = getenv("NHMC_PAIR_WAVES");                 // experiment switch (tools/pair_bench.py): 4 waves = 2 x 2 MFMA tiles per wave
-  if (v && v[0] == '4') return pair256_nw<EPI, PRECLIP, 4>(IN, S1, S2, OUT, Dmap, aux, ws, n_img, channels, st, vj);
-  return pair256_nw<EPI, PRECLIP, 8>(IN, S1, S2, OUT, Dmap, aux, ws, n_img, channels, st, vj);
+  return pair256_nw<EPI, PRECLIP, 8, TOUT>(IN, S1, S2, OUT, Dmap, aux, ws, n_img, channels, st, vj);
 }
 
 int tile_of2(int R, int C) { return (R % 128 == 0 && C % 128 == 0) ? 128 : ((R % 64 == 0 && C % 64 == 0) ? 64 : 32); }
 
 // OUT[R][C] = IN[K][R]^T * S[K][C] per image; K % 32 == 0, R % 32 == 0, C % 32 == 0.
-template <int EPI, bool PRECLIP>
+template <int EPI, bool PRECLIP, bool TOUT = false>
 int gemm_krc(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
              int channels, int K, int R, int C, hipStream_t st, VjpArgs vj = VjpArgs{}) {
   const int T = tile_of2(R, C);
   dim3 grid((unsigned)((C / T) * (R / T) * n_img));
   if (T == 128)
-    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
+    NHMC_LAUNCH((k_sgemm<128, 2, EPI, PRECLIP, TOUT>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   else if (T == 64)
-    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
+    NHMC_LAUNCH((k_sgemm<64, 2, EPI, PRECLIP, TOUT>), grid, dim3(256), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   else
-    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
+    NHMC_LAUNCH((k_sgemm<32, 1, EPI, PRECLIP, TOUT>), grid, dim3(64), 0, st, IN, S, OUT, Dmap, aux, ws, K, R, C, channels, vj);
   return nhmc_launch_status();
 }
 
-template <int EPI, bool PRECLIP>
+template <int EPI, bool PRECLIP, bool TOUT = false>
 int gemm(const float* IN, const float* S, float* OUT, const float* Dmap, const float* aux, double* ws, int n_img,
          int channels, int d, hipStream_t st, VjpArgs vj = VjpArgs{}) {
-  return gemm_krc<EPI, PRECLIP>(IN, S, OUT, Dmap, aux, ws, n_img, channels, d, d, d, st, vj);
+  return gemm_krc<EPI, PRECLIP, TOUT>(IN, S, OUT, Dmap, aux, ws, n_img, channels, d, d, d, st, vj);
 }
 
 int tile_of(int d) { return d % 128 == 0 ? 128 : (d % 64 == 0 ? 64 : 32); }
@@ -497,80 +528,77 @@ extern "C" int nhmc_spectral_apply(const float* x, const float* L, const float* 
   return gemm<EPI_NONE, false>(tmp, RoT, out, nullptr, nullptr, nullptr, n, channels, dim, st);                 // Lo . Ro^T
 }
 
-// Data term for the spectral operator.  `factors` is the packed resident block [8][d][d] (row-major):
-// U1, U2, V1, V2, U1^T, U2^T, V1^T, V2^T.
-extern "C" int nhmc_data_spectral(const float* xt, const float* y, const float* factors, const float* Dmap,
-                                  int apply_clip, float* g_xt, double* loss_ws, float* tmp, int n_chains,
-                                  int channels, int dim, nhmc_stream_t stream) {
-  if (!xt || !y || !factors || !Dmap || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
-  if (bad(n_chains, channels, dim)) return NHMC_ERR_SHAPE;
+// Data term for the spectral operator, in the reference's rounding sequence INCLUDING autograd's.  `factors` is the
+// packed resident block [8][d][d] (row-major): U1, U2, V1, V2, U1^T, U2^T, V1^T, V2^T.
+//   forward  (Hfuncs.py:65-71, Vt :493-499, U :501-509):  A = D o ((V1^T x) V2),  H x = (U1 A) U2^T   -- left factor first
+//   backward (autograd of those matmuls):  dA4 = r~ U2,  dA3 = U1^T dA4,  dA2 = D o dA3,  dA1 = dA2 V2^T,  g = V1 dA1
+//                                                                                    -- RIGHT factor first, r~ = -2 r
+// Every product is an exact k-ascending FMA chain from zero on the MFMA (v_mfma_f32_32x32x2_f32), which is also what
+// torch's CPU sgemm computes (tools/mfma_bits.py), so with the same stage order the data term is the reference's bits.
+// The kernel form OUT = IN^T S multiplies from the left; the backward's right-first order is run on TRANSPOSED operands:
+// the forward's last product stores r^T (TOUT; `yT` = the observation transposed per channel plane, constant over a run)
+// and  (r^T)^T U2 = r U2, ... the adjoint's last product yields g^T, transposed back in its epilogue (TOUT) where the
+// clip mask / the last DDIM step's VJP are applied in natural coordinates.  DmapT = D transposed per channel.
+namespace {
+template <bool PRECLIP>
+int spectral_chain(const float* x, const float* yT, const float* factors, const float* Dmap, const float* DmapT,
+                   const float* mask_or_xt, const VjpArgs* vjp, float* g_xt, double* loss_ws, float* tmp, int n,
+                   int channels, int dim, hipStream_t st) {
   const int64_t dd = (int64_t)dim * dim;
-  if (!nhmc_aligned16(xt) || !nhmc_aligned16(y) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
-      !nhmc_aligned16(tmp))
-    return NHMC_ERR_ALIGN;
   const float *U1 = factors, *U2 = factors + dd, *V1 = factors + 2 * dd, *V2 = factors + 3 * dd;
   const float *U1T = U1 + 4 * dd, *U2T = U1 + 5 * dd, *V1T = U1 + 6 * dd, *V2T = U1 + 7 * dd;
-  hipStream_t st = nhmc_s(stream);
-  const int n = n_chains * channels;
   float* A = tmp;
   float* B = tmp + (int64_t)n * dd;
   int rc;
   if (dim == 256 && pairs_enabled()) {                      // two products per launch, intermediates stay in LDS
-    if (apply_clip) { if ((rc = pair256<EPI_MULD, true>(xt, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc; }
-    else            { if ((rc = pair256<EPI_MULD, false>(xt, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc; }
-    if ((rc = pair256<EPI_RESID, false>(A, U1T, U2T, B, nullptr, y, loss_ws, n, channels, st))) return rc;
-    if ((rc = pair256<EPI_MULD, false>(B, U1, U2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;
-    return pair256<EPI_GRAD, false>(A, V1T, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, st);
+    if ((rc = pair256<EPI_MULD, PRECLIP>(x, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;          // D o (V1^T x V2)
+    if ((rc = pair256<EPI_RESID, false, true>(A, U1T, U2T, B, nullptr, yT, loss_ws, n, channels, st))) return rc;      // r^T
+    if ((rc = pair256<EPI_MULD, false>(B, U2, U1, A, DmapT, nullptr, nullptr, n, channels, st))) return rc;            // (D o (U1^T (r U2)))^T
+    if (vjp) return pair256<EPI_VJP, false, true>(A, V2T, V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, st, *vjp);
+    return pair256<EPI_GRAD, false, true>(A, V2T, V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, st);         // (V1 ((.) V2^T))
   }
-  // r = y - U1 (D o (V1^T clip(xt) V2)) U2^T
-  if (apply_clip) { if ((rc = gemm<EPI_NONE, true>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
-  else            { if ((rc = gemm<EPI_NONE, false>(xt, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc; }
-  if ((rc = gemm<EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_RESID, false>(A, U2T, B, nullptr, y, loss_ws, n, channels, dim, st))) return rc;
-  // g = -2 V1 (D o (U1^T r U2)) V2^T  (x) mask
-  if ((rc = gemm<EPI_NONE, false>(B, U1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  return gemm<EPI_GRAD, false>(A, V2T, g_xt, nullptr, apply_clip ? xt : nullptr, nullptr, n, channels, dim, st);
+  if ((rc = gemm<EPI_NONE, PRECLIP>(x, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;            // (V1^T x)^T
+  if ((rc = gemm<EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;                 // D o (V1^T x V2)
+  if ((rc = gemm<EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;             // (U1 A)^T
+  if ((rc = gemm<EPI_RESID, false, true>(A, U2T, B, nullptr, yT, loss_ws, n, channels, dim, st))) return rc;           // r^T = (y - U1 A U2^T)^T
+  if ((rc = gemm<EPI_NONE, false>(B, U2, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;              // r U2
+  if ((rc = gemm<EPI_MULD, false>(A, U1, B, DmapT, nullptr, nullptr, n, channels, dim, st))) return rc;                // (D o (U1^T r U2))^T
+  if ((rc = gemm<EPI_NONE, false>(B, V2T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;             // (.) V2^T
+  if (vjp) return gemm<EPI_VJP, false, true>(A, V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, dim, st, *vjp);
+  return gemm<EPI_GRAD, false, true>(A, V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, dim, st);               // V1 (.)
+}
+}  // namespace
+
+extern "C" int nhmc_data_spectral(const float* xt, const float* yT, const float* factors, const float* Dmap,
+                                  const float* DmapT, int apply_clip, float* g_xt, double* loss_ws, float* tmp,
+                                  int n_chains, int channels, int dim, nhmc_stream_t stream) {
+  if (!xt || !yT || !factors || !Dmap || !DmapT || !g_xt || !loss_ws || !tmp) return NHMC_ERR_ARG;
+  if (bad(n_chains, channels, dim)) return NHMC_ERR_SHAPE;
+  if (!nhmc_aligned16(xt) || !nhmc_aligned16(yT) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(tmp) || !nhmc_aligned16(Dmap) || !nhmc_aligned16(DmapT))
+    return NHMC_ERR_ALIGN;
+  const int n = n_chains * channels;
+  if (apply_clip)
+    return spectral_chain<true>(xt, yT, factors, Dmap, DmapT, xt, nullptr, g_xt, loss_ws, tmp, n, channels, dim, nhmc_s(stream));
+  return spectral_chain<false>(xt, yT, factors, Dmap, DmapT, nullptr, nullptr, g_xt, loss_ws, tmp, n, channels, dim, nhmc_s(stream));
 }
 
 // Data term + VJP of the last DDIM step for the spectral operator: xt_next = the clipped decode (what k_mix_fwd with
 // final_clip wrote), (xt, e) the step's inputs.  The eighth product's epilogue writes g_xt and g_e directly.
-extern "C" int nhmc_data_spectral_vjp(const float* xt_next, const float* y, const float* factors, const float* Dmap,
-                                      const float* xt, const float* e, int e_channels, const float* at,
-                                      const float* at_next, float* g_xt, float* g_e, double* loss_ws, float* tmp,
-                                      int n_chains, int channels, int dim, nhmc_stream_t stream) {
-  if (!xt_next || !y || !factors || !Dmap || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
+extern "C" int nhmc_data_spectral_vjp(const float* xt_next, const float* yT, const float* factors, const float* Dmap,
+                                      const float* DmapT, const float* xt, const float* e, int e_channels,
+                                      const float* at, const float* at_next, float* g_xt, float* g_e, double* loss_ws,
+                                      float* tmp, int n_chains, int channels, int dim, nhmc_stream_t stream) {
+  if (!xt_next || !yT || !factors || !Dmap || !DmapT || !xt || !e || !at || !at_next || !g_xt || !g_e || !loss_ws || !tmp)
     return NHMC_ERR_ARG;
   if (bad(n_chains, channels, dim) || (e_channels != channels && e_channels != 2 * channels)) return NHMC_ERR_SHAPE;
-  const int64_t dd = (int64_t)dim * dim;
-  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(y) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
-      !nhmc_aligned16(tmp) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_e) || !nhmc_aligned16(Dmap))
+  if (!nhmc_aligned16(xt_next) || !nhmc_aligned16(yT) || !nhmc_aligned16(factors) || !nhmc_aligned16(g_xt) ||
+      !nhmc_aligned16(tmp) || !nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_e) || !nhmc_aligned16(Dmap) ||
+      !nhmc_aligned16(DmapT))
     return NHMC_ERR_ALIGN;
-  const float *U1 = factors, *U2 = factors + dd, *V1 = factors + 2 * dd, *V2 = factors + 3 * dd;
-  const float *U1T = U1 + 4 * dd, *U2T = U1 + 5 * dd, *V1T = U1 + 6 * dd, *V2T = U1 + 7 * dd;
-  hipStream_t st = nhmc_s(stream);
-  const int n = n_chains * channels;
-  float* A = tmp;
-  float* B = tmp + (int64_t)n * dd;
-  int rc;
-  if (dim == 256 && pairs_enabled()) {
-    const VjpArgs vjp{e, g_e, at, at_next, e_channels};
-    if ((rc = pair256<EPI_MULD, false>(xt_next, V1, V2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;
-    if ((rc = pair256<EPI_RESID, false>(A, U1T, U2T, B, nullptr, y, loss_ws, n, channels, st))) return rc;
-    if ((rc = pair256<EPI_MULD, false>(B, U1, U2, A, Dmap, nullptr, nullptr, n, channels, st))) return rc;
-    return pair256<EPI_VJP, false>(A, V1T, V2T, g_xt, nullptr, xt, nullptr, n, channels, st, vjp);
-  }
-  if ((rc = gemm<EPI_NONE, false>(xt_next, V1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_MULD, false>(A, V2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_NONE, false>(B, U1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_RESID, false>(A, U2T, B, nullptr, y, loss_ws, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_NONE, false>(B, U1, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_MULD, false>(A, U2, B, Dmap, nullptr, nullptr, n, channels, dim, st))) return rc;
-  if ((rc = gemm<EPI_NONE, false>(B, V1T, A, nullptr, nullptr, nullptr, n, channels, dim, st))) return rc;
-  const VjpArgs vj{e, g_e, at, at_next, e_channels};
-  return gemm<EPI_VJP, false>(A, V2T, g_xt, nullptr, xt, nullptr, n, channels, dim, st, vj);
+  const VjpArgs vjp{e, g_e, at, at_next, e_channels};
+  return spectral_chain<false>(xt_next, yT, factors, Dmap, DmapT, xt, &vjp, g_xt, loss_ws, tmp, n_chains * channels, channels,
+                               dim, nhmc_s(stream));
 }
 
 // ---- the data term with the residual taken in the left singular basis ------------------------------------------------
@@ -688,11 +716,13 @@ extern "C" int nhmc_srconv_tiles(int channels, int small_dim) {
 namespace {
 struct SrconvFactors { const float *V1, *V1T, *U, *UT, *S; };   // [d][sd], [sd][d], [sd][sd], [sd][sd], [sd][sd]
 
-// r = y - U (S o (V1^T x V1)) U^T with loss partials; then H^T r through its four products, the last one with the
-// gradient epilogue (`vjp` == nullptr: g = -2 H^T r (x) clip mask of `mask_src` when given) or the last DDIM step's VJP.
+// r = y - U (S o (V1^T x V1)) U^T with loss partials, stored transposed (TOUT; yT = the observation transposed per
+// plane); then the adjoint in autograd's order -- r U, U^T (.), S o, (.) V1^T, V1 (.) : right factor first, run on the
+// transposed operands as in spectral_chain -- the last product transposing back under the gradient epilogue (`vjp` ==
+// nullptr: g = -2 H^T r (x) clip mask of `mask_or_xt` when given) or the last DDIM step's VJP.  S is symmetric.
 // tmp: float[n * (d*sd + 3*sd*sd)].
 template <bool PRECLIP>
-int srconv_chain(const float* x, const float* y, const SrconvFactors& f, const float* mask_or_xt, const VjpArgs* vjp,
+int srconv_chain(const float* x, const float* yT, const SrconvFactors& f, const float* mask_or_xt, const VjpArgs* vjp,
                  float* g_xt, double* loss_ws, float* tmp, int n, int channels, int d, int sd, hipStream_t st) {
   float* T1 = tmp;                                    // [d][sd], later [sd][d]
   float* Z = T1 + (int64_t)n * d * sd;                // [sd][sd]
@@ -702,12 +732,12 @@ int srconv_chain(const float* x, const float* y, const SrconvFactors& f, const f
   if ((rc = gemm_krc<EPI_NONE, PRECLIP>(x, f.V1, T1, nullptr, nullptr, nullptr, n, channels, d, d, sd, st))) return rc;   // (V1^T x)^T
   if ((rc = gemm_krc<EPI_MULD, false>(T1, f.V1, Z, f.S, nullptr, nullptr, n, 1, d, sd, sd, st))) return rc;              // S o (V1^T x V1)
   if ((rc = gemm_krc<EPI_NONE, false>(Z, f.UT, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, sd, st))) return rc;  // (U Z)^T
-  if ((rc = gemm_krc<EPI_RESID, false>(T2, f.UT, Rr, nullptr, y, loss_ws, n, channels, sd, sd, sd, st))) return rc;      // r = y - U Z U^T
-  if ((rc = gemm_krc<EPI_NONE, false>(Rr, f.U, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, sd, st))) return rc;  // (U^T r)^T
-  if ((rc = gemm_krc<EPI_MULD, false>(T2, f.U, Z, f.S, nullptr, nullptr, n, 1, sd, sd, sd, st))) return rc;              // S o (U^T r U)
-  if ((rc = gemm_krc<EPI_NONE, false>(Z, f.V1T, T1, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;  // (V1 W)^T
-  if (vjp) return gemm_krc<EPI_VJP, false>(T1, f.V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, sd, d, d, st, *vjp);
-  return gemm_krc<EPI_GRAD, false>(T1, f.V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, sd, d, d, st);
+  if ((rc = gemm_krc<EPI_RESID, false, true>(T2, f.UT, Rr, nullptr, yT, loss_ws, n, channels, sd, sd, sd, st))) return rc;  // r^T
+  if ((rc = gemm_krc<EPI_NONE, false>(Rr, f.U, T2, nullptr, nullptr, nullptr, n, channels, sd, sd, sd, st))) return rc;  // r U
+  if ((rc = gemm_krc<EPI_MULD, false>(T2, f.U, Z, f.S, nullptr, nullptr, n, 1, sd, sd, sd, st))) return rc;              // (S o (U^T r U))^T
+  if ((rc = gemm_krc<EPI_NONE, false>(Z, f.V1T, T1, nullptr, nullptr, nullptr, n, channels, sd, sd, d, st))) return rc;  // (.) V1^T
+  if (vjp) return gemm_krc<EPI_VJP, false, true>(T1, f.V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, sd, d, d, st, *vjp);
+  return gemm_krc<EPI_GRAD, false, true>(T1, f.V1T, g_xt, nullptr, mask_or_xt, nullptr, n, channels, sd, d, d, st);     // V1 (.)
 }
 
 bool srconv_bad_shape(int n_chains, int channels, int dim, int small_dim) {
@@ -717,6 +747,7 @@ bool srconv_bad_shape(int n_chains, int channels, int dim, int small_dim) {
 }  // namespace
 
 // Data term: r = y - H(clip(xt)), loss partials (nhmc_srconv_tiles per chain), g = -2 H^T r (x) clip mask.
+// y = the observation TRANSPOSED per channel plane ([n_chains][C][sd][sd], each plane transposed).
 extern "C" int nhmc_data_srconv(const float* xt, const float* y, const float* V1, const float* V1T, const float* U,
                                 const float* UT, const float* S, int apply_clip, float* g_xt, double* loss_ws, float* tmp,
                                 int n_chains, int channels, int dim, int small_dim, nhmc_stream_t stream) {

@@ -439,34 +439,43 @@ def cs_Ht(y, kslot, channels, dim):
     return x.reshape(B, -1)
 
 
-def data_cs(xt, y, kslot, apply_clip=True, loss_out=None):
+def _cs_tmp(xt, dim):
+    return torch.empty((1 if dim == 256 else 2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+
+
+def data_cs(xt, y_spec, apply_clip=True, loss_out=None):
+    """y_spec: the observation in spectrum layout [B, C, d, d], NaN where not observed (nhmc.h, nhmc_data_cs)."""
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
+    if y_spec.numel() != xt.numel():
+        raise _lib.NhmcError('data_cs: y_spec must have one entry per image element (spectrum layout)')
     tiles = lib.nhmc_cs_tiles(Cc, dim)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
-    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    tmp = _cs_tmp(xt, dim)
     g = torch.empty_like(xt)
-    rc = lib.nhmc_data_cs(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(kslot, torch.int32), int(apply_clip),
-                          _p(g), _p(ws), _p(tmp), B, Cc, dim, y.shape[1], _stream())
+    rc = lib.nhmc_data_cs(_p(xt, torch.float32, 'xt'), _p(y_spec, torch.float32, 'y_spec'), int(apply_clip),
+                          _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_cs')
     return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_cs_vjp(xt_next, y, kslot, xt, e, at, at_next, g_e_out=None, loss_out=None):
-    """Walsh-Hadamard CS data term on the clipped decode + VJP of the last DDIM step in the last column pass
-    -> (loss [B] float64, g_xt, g_e)."""
+def data_cs_vjp(xt_next, y_spec, xt, e, at, at_next, g_e_out=None, loss_out=None):
+    """Walsh-Hadamard CS data term on the clipped decode + VJP of the last DDIM step in the last row pass
+    -> (loss [B] float64, g_xt, g_e).  y_spec: as in data_cs."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     dim = xt.shape[2]
+    if y_spec.numel() != xt.numel():
+        raise _lib.NhmcError('data_cs_vjp: y_spec must have one entry per image element (spectrum layout)')
     at, at_next = _alpha(at, B, xt.device), _alpha(at_next, B, xt.device)
     tiles = lib.nhmc_cs_tiles(Cc, dim)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
-    tmp = torch.empty((2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
+    tmp = _cs_tmp(xt, dim)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)
-    rc = lib.nhmc_data_cs_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'), _p(kslot, torch.int32),
+    rc = lib.nhmc_data_cs_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y_spec, torch.float32, 'y_spec'),
                               _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next), _p(g_xt),
-                              _p(g_e), _p(ws), _p(tmp), B, Cc, dim, y.shape[1], _stream())
+                              _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_cs_vjp')
     return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 
@@ -556,25 +565,33 @@ def spectral_project(y, L, R):
     return out
 
 
-def data_spectral(xt, y, factors, Dmap, apply_clip=True, loss_out=None, projected=False):
+def data_spectral(xt, y, factors, Dmap, apply_clip=True, loss_out=None, projected=False, DmapT=None):
     """factors: packed [8,d,d] = U1,U2,V1,V2,U1^T,U2^T,V1^T,V2^T -> (loss [B] float64, g_xt).
-    projected: `y` is spectral_project(y, U1, U2) and the four-product form runs."""
+    Eight-product (reference-order) form: `y` is the observation with every channel plane TRANSPOSED and DmapT the
+    multiplier map likewise (nhmc.h, nhmc_data_spectral).  projected: `y` is spectral_project(y, U1, U2) (natural
+    orientation) and the four-product form runs."""
     lib = _lib.load()
     B, Cc, dim = xt.shape[0], xt.shape[1], xt.shape[2]
     tiles = lib.nhmc_spectral_tiles(Cc, dim)
     ws = torch.empty(B * tiles, dtype=torch.float64, device=xt.device)
     tmp = torch.empty((1 if projected else 2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
     g = torch.empty_like(xt)
-    fn = lib.nhmc_data_spectral_proj if projected else lib.nhmc_data_spectral
-    rc = fn(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(factors, torch.float32, 'factors'),
-            _p(Dmap, torch.float32), int(apply_clip), _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    if projected:
+        rc = lib.nhmc_data_spectral_proj(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'y'), _p(factors, torch.float32, 'factors'),
+                                         _p(Dmap, torch.float32), int(apply_clip), _p(g), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    else:
+        if DmapT is None:
+            raise _lib.NhmcError('data_spectral: the eight-product form needs DmapT (Dmap with every plane transposed)')
+        rc = lib.nhmc_data_spectral(_p(xt, torch.float32, 'xt'), _p(y, torch.float32, 'yT'), _p(factors, torch.float32, 'factors'),
+                                    _p(Dmap, torch.float32), _p(DmapT, torch.float32, 'DmapT'), int(apply_clip), _p(g), _p(ws), _p(tmp),
+                                    B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_spectral')
     return sum_partials(ws, tiles, B, out=loss_out), g
 
 
-def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None, loss_out=None, projected=False):
+def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=None, loss_out=None, projected=False, DmapT=None):
     """Spectral data term on the clipped decode `xt_next` + VJP of the last DDIM step (inputs xt, e) in the last
-    product's epilogue -> (loss [B] float64, g_xt, g_e).  projected: as in data_spectral."""
+    product's epilogue -> (loss [B] float64, g_xt, g_e).  y / DmapT / projected: as in data_spectral."""
     lib = _lib.load()
     B, Cc, hw, ec = _mix_shapes(xt, e)
     dim = xt.shape[2]
@@ -584,11 +601,18 @@ def data_spectral_vjp(xt_next, y, factors, Dmap, xt, e, at, at_next, g_e_out=Non
     tmp = torch.empty((1 if projected else 2,) + tuple(xt.shape), dtype=torch.float32, device=xt.device)
     g_xt = torch.empty_like(xt)
     g_e = g_e_out if g_e_out is not None else torch.zeros_like(e)          # channels [0, C) are written
-    fn = lib.nhmc_data_spectral_proj_vjp if projected else lib.nhmc_data_spectral_vjp
-    rc = fn(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'),
-                                    _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32),
-                                    _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
-                                    _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    if projected:
+        rc = lib.nhmc_data_spectral_proj_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'y'),
+                                             _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32),
+                                             _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                             _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())
+    else:
+        if DmapT is None:
+            raise _lib.NhmcError('data_spectral_vjp: the eight-product form needs DmapT (Dmap with every plane transposed)')
+        rc = lib.nhmc_data_spectral_vjp(_p(xt_next, torch.float32, 'xt_next'), _p(y, torch.float32, 'yT'),
+                                        _p(factors, torch.float32, 'factors'), _p(Dmap, torch.float32), _p(DmapT, torch.float32, 'DmapT'),
+                                        _p(xt, torch.float32, 'xt'), _p(e, torch.float32, 'e'), ec, _p(at), _p(at_next),
+                                        _p(g_xt), _p(g_e), _p(ws), _p(tmp), B, Cc, dim, _stream())
     _lib.check(rc, 'nhmc_data_spectral_vjp')
     return sum_partials(ws, tiles, B, out=loss_out), g_xt, g_e
 

@@ -189,6 +189,7 @@ class Deblurring2D(H_functions):
         self.Dmap = D.detach().cpu().float().contiguous().to(device)
         Dp = torch.where(self.Dmap != 0, 1.0 / self.Dmap, torch.zeros_like(self.Dmap))
         self.Dpinv = Dp.contiguous()
+        self.DmapT = self.Dmap.transpose(-1, -2).contiguous()       # the adjoint chain runs on transposed operands (nhmc.h)
         # Opt-in (projected=True / NHMC_SPECTRAL_PROJECTED=1 / --spectral_projected): the data term takes the residual
         # in the left singular basis -- four products instead of eight (nhmc_data_spectral_proj), valid when U1, U2 are
         # orthogonal to fp32 accuracy, which full SVDs are.  The default stays the reference's eight-product rounding
@@ -220,35 +221,42 @@ class Deblurring2D(H_functions):
         y = _img(vec, self.channels, self.img_dim)
         return K.spectral_apply(y, self._f(0), self._f(1), self.Dpinv, self._f(6), self._f(7)).reshape(y.shape[0], -1)
 
-    def project_observation(self, y):
-        """y^ = U1^T y U2, cached per observation buffer: the sampler passes the same y_0 (or the same chunk views of it)
-        in every leapfrog step of a run.  An entry pins the buffer's storage, so its address cannot be handed to another
-        tensor while the entry lives; an in-place write bumps the version and misses.
-        While the stream is being captured into a hipGraph the cache is bypassed in both directions: the projection must
-        be a launch OF the graph, because a replay refills the static observation buffer with another chunk's y (the
-        engine keys its graphs by shape, sampler.LeapfrogEngine._graphed_chunk) -- a cached y^ of the buffer's warm-up
-        content would silently serve every later chunk."""
+    def _observation_form(self, y, make, kind):
+        """A constant transform of the observation (`make(y)`), cached per observation buffer: the sampler passes the
+        same y_0 (or the same chunk views of it) in every leapfrog step of a run.  An entry pins the buffer's storage, so
+        its address cannot be handed to another tensor while the entry lives; an in-place write bumps the version and
+        misses.  While the stream is being captured into a hipGraph the cache is bypassed in both directions: the
+        transform must be a launch OF the graph, because a replay refills the static observation buffer with another
+        chunk's y (the engine keys its graphs by shape, sampler.LeapfrogEngine._graphed_chunk) -- a cached form of the
+        buffer's warm-up content would silently serve every later chunk."""
         if y.is_cuda and torch.cuda.is_current_stream_capturing():
-            return K.spectral_project(y, self._f(0), self._f(1))
-        key = (y.data_ptr(), y._version, tuple(y.shape))
+            return make(y)
+        key = (kind, y.data_ptr(), y._version, tuple(y.shape))
         hit = self._y_proj.get(key)
         if hit is None:
             if len(self._y_proj) >= 16:
                 self._y_proj.pop(next(iter(self._y_proj)))
-            hit = (K.spectral_project(y, self._f(0), self._f(1)), y.untyped_storage())
+            hit = (make(y), y.untyped_storage())
             self._y_proj[key] = hit
         return hit[0]
 
+    def project_observation(self, y):
+        """y^ = U1^T y U2 (the four-product form's observation)."""
+        return self._observation_form(y, lambda t: K.spectral_project(t, self._f(0), self._f(1)), 'projected')
+
     def _obs(self, y, shape):
+        """What the data-term kernels take as observation: y^ for the projected form, else y with every channel plane
+        transposed (the adjoint chain runs right-factor-first on transposed operands; plain data movement)."""
         y = y.reshape(shape)
+        make = (lambda t: K.spectral_project(t, self._f(0), self._f(1))) if self.projected else \
+            (lambda t: t.transpose(-1, -2).contiguous())
         if y.is_contiguous():
-            return self.project_observation(y) if self.projected else y
-        y = y.contiguous()                                          # a temporary: projected afresh, never cached
-        return K.spectral_project(y, self._f(0), self._f(1)) if self.projected else y
+            return self._observation_form(y, make, 'projected' if self.projected else 'transposed')
+        return make(y.contiguous())                                 # a temporary: never cached
 
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
         return K.data_spectral(xt, self._obs(y, xt.shape), self.factors, self.Dmap, apply_clip, loss_out=loss_out,
-                               projected=self.projected)
+                               projected=self.projected, DmapT=self.DmapT)
 
     fused_wants_decode = True              # the engine hands over the clipped decode it already holds
 
@@ -258,7 +266,7 @@ class Deblurring2D(H_functions):
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
         return K.data_spectral_vjp(xt_next, self._obs(y, xt_in.shape), self.factors, self.Dmap, xt_in, e, at,
-                                   at_next, g_e_out=g_e_out, loss_out=loss_out, projected=self.projected)
+                                   at_next, g_e_out=g_e_out, loss_out=loss_out, projected=self.projected, DmapT=self.DmapT)
 
 
 class Deblurring(Deblurring2D):
@@ -312,6 +320,8 @@ class WalshHadamardCS(H_functions):
         kslot[perm.detach().cpu().long()[:rows]] = torch.arange(rows, dtype=torch.int32)
         self.kslot = kslot.to(device)
         self._singulars = torch.ones(self.M, device=device)
+        self._pos = perm.detach().cpu().long()[:rows].to(device)      # spectrum position of observation row k
+        self._y_spec = {}
 
     def singulars(self):
         return self._singulars
@@ -324,8 +334,28 @@ class WalshHadamardCS(H_functions):
 
     H_pinv = Ht
 
+    def spectrum_observation(self, y):
+        """y [B, K*C] (row k, channel c at k*C + c) -> [B, C, d, d] in the transform's own layout, y_spec[b, c, perm[k]] =
+        y[b, k*C + c] and NaN where the spectrum is not observed: what the data-term kernels read (coalesced, no gather).
+        Constant over a run: cached per observation buffer (pinned storage + version, as Deblurring2D does) and never
+        across a hipGraph capture.  Plain data movement."""
+        def make(t):
+            B, d = t.shape[0], self.img_dim
+            spec = torch.full((B, self.channels, d * d), float('nan'), dtype=torch.float32, device=t.device)
+            spec[:, :, self._pos] = t.reshape(B, -1, self.channels).permute(0, 2, 1)
+            return spec.reshape(B, self.channels, d, d)
+        if not y.is_contiguous() or (y.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return make(y)
+        key = (y.data_ptr(), y._version, tuple(y.shape))
+        hit = self._y_spec.get(key)
+        if hit is None:
+            if len(self._y_spec) >= 16:
+                self._y_spec.pop(next(iter(self._y_spec)))
+            hit = self._y_spec[key] = (make(y), y.untyped_storage())
+        return hit[0]
+
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
-        return K.data_cs(xt, y, self.kslot, apply_clip, loss_out=loss_out)
+        return K.data_cs(xt, self.spectrum_observation(y), apply_clip, loss_out=loss_out)
 
     fused_wants_decode = True
 
@@ -333,7 +363,7 @@ class WalshHadamardCS(H_functions):
         """Data term + VJP of the last DDIM step (in the last column pass) -> (loss, g_xt, g_e)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
-        return K.data_cs_vjp(xt_next, y.contiguous(), self.kslot, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
+        return K.data_cs_vjp(xt_next, self.spectrum_observation(y), xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
 
 
 def strided_conv_matrix(kernel, img_dim, stride):
@@ -385,6 +415,7 @@ class SRConv(H_functions):
         self.V1, self.V1T, self.U, self.UT, self.S, self.Sinv = dev(V1), dev(V1.t()), dev(U), dev(U.t()), dev(S), dev(Sinv)
         self.factors = (self.V1, self.V1T, self.U, self.UT, self.S)
         self.M = channels * sd * sd
+        self._y_t = {}
 
     def _planes(self, v, dim):
         return v.reshape(-1, dim, dim).contiguous()
@@ -405,8 +436,23 @@ class SRConv(H_functions):
     def H_pinv(self, vec):
         return self._adjoint(vec, self.Sinv)
 
+    def _obs_t(self, y):
+        """The observation with every channel plane transposed (what nhmc_data_srconv takes), cached per buffer as
+        Deblurring2D._observation_form does, and never across a graph capture."""
+        sd = self.small_dim
+        make = lambda t: t.reshape(t.shape[0], self.channels, sd, sd).transpose(-1, -2).contiguous()
+        if not y.is_contiguous() or (y.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return make(y)
+        key = (y.data_ptr(), y._version, tuple(y.shape))
+        hit = self._y_t.get(key)
+        if hit is None:
+            if len(self._y_t) >= 16:
+                self._y_t.pop(next(iter(self._y_t)))
+            hit = self._y_t[key] = (make(y), y.untyped_storage())
+        return hit[0]
+
     def data_term(self, xt, y, apply_clip=True, loss_out=None):
-        return K.data_srconv(xt, y.contiguous(), self.factors, apply_clip, loss_out=loss_out)
+        return K.data_srconv(xt, self._obs_t(y), self.factors, apply_clip, loss_out=loss_out)
 
     fused_wants_decode = True
 
@@ -414,7 +460,7 @@ class SRConv(H_functions):
         """Data term + VJP of the last DDIM step (in the last product's epilogue) -> (loss, g_xt, g_e)."""
         if xt_next is None:
             xt_next = K.ddim_mix_fwd(xt_in, e, at, at_next, final_clip=True)['xt_next']
-        return K.data_srconv_vjp(xt_next, y.contiguous(), self.factors, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
+        return K.data_srconv_vjp(xt_next, self._obs_t(y), self.factors, xt_in, e, at, at_next, g_e_out=g_e_out, loss_out=loss_out)
 
 
 def bicubic_taps(factor, a=-0.5):

@@ -88,6 +88,8 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.nhmc_grad_cache_flip(null, a16, 1, null) == 1
     assert lib.nhmc_hamiltonian_cached(a16, 1, a16, null, 1, a16, 1.0, a16, null, 1, null) == 1                            # no sel
     assert lib.nhmc_sandwich_rect(a16, a16, a16, null, a16, a16, 1, 64, 64, 48, 64, null) == 3                             # C1 % 32
+    assert lib.nhmc_data_spectral(a16, a16, a16, a16, null, 1, a16, a16, a16, 1, 3, 64, null) == 1                          # no transposed multiplier map
+    assert lib.nhmc_data_spectral_vjp(a16, null, a16, a16, a16, a16, a16, 6, a16, a16, a16, a16, a16, a16, 1, 3, 64, null) == 1  # no transposed observation
     assert lib.nhmc_data_srconv(a16, a16, a16, a16, a16, a16, null, 1, a16, a16, a16, 1, 3, 64, 32, null) == 1              # no multiplier map
     assert lib.nhmc_data_srconv(a16, a16, a16, a16, a16, a16, a16, 1, a16, a16, a16, 1, 3, 64, 128, null) == 3             # small_dim > dim
     assert lib.nhmc_mass_from_variance(a16, 5, null, null, a16, a16, a16, a16, 1 << 20, 1, 768, null) == 1                 # no mass table

@@ -205,8 +205,29 @@ def test_spectral_operator_and_data_term(dim, B):
     assert rel(op.Ht(dev(y)), ref.Ht(y)) < 2e-5
     assert rel(op.H_pinv(dev(y)), ref.H_pinv(y)) < 2e-5
     loss_ref, g_ref = hmc_ref.data_term(xt, ref, y)
-    loss, g = K.data_spectral(dev(xt), dev(y), op.factors, op.Dmap, apply_clip=True)
+    yT = dev(y).reshape(B, 3, dim, dim).transpose(-1, -2).contiguous()          # the kernel takes the planes transposed
+    loss, g = K.data_spectral(dev(xt), yT, op.factors, op.Dmap, apply_clip=True, DmapT=op.DmapT)
     assert rel(loss, loss_ref) < 2e-5 and rel(g, g_ref) < 2e-5
+    loss_op, g_op = op.data_term(dev(xt), dev(y), apply_clip=True)             # the operator does that transposition itself
+    assert torch.equal(g_op, g) and torch.equal(loss_op, loss)
+
+
+@pytest.mark.parametrize('dim', [32, 64])
+def test_spectral_data_term_is_the_reference_arithmetic_bit_for_bit(dim):
+    """Every MFMA product is an exact k-ascending FMA chain from zero -- what torch's CPU sgemm computes (tools/mfma_bits.py,
+    K <= 64 on the GPU box's host; up to 256 on the build container's) -- the forward multiplies by the left factor first
+    as Hfuncs.py:493-509 does and the adjoint by the right factor first as autograd does: the gradient of the data term is
+    the oracle's autograd gradient, bit for bit (the loss differs in its summation only)."""
+    ref, op = _aniso(dim)
+    g_ = gen(80 + dim)
+    B = 3
+    xt = torch.randn(B, 3, dim, dim, generator=g_) * 0.8
+    y = torch.randn(B, ref.M, generator=g_)
+    assert torch.equal(op.H(dev(xt)).cpu(), ref.H(xt)) and torch.equal(op.Ht(dev(y)).cpu(), ref.Ht(y))
+    loss_ref, g_ref = hmc_ref.data_term(xt, ref, y)
+    loss, g = op.data_term(dev(xt), dev(y), apply_clip=True)
+    assert torch.equal(g.cpu(), g_ref), float((g.cpu() - g_ref).abs().max() / g_ref.abs().max())
+    assert rel(loss, loss_ref) < 1e-6
 
 
 def test_spectral_against_reference_operator_data(golden):

@@ -255,6 +255,56 @@ def test_ffhq_width_latent_model_runs_one_trajectory():
     assert img.shape == (2, 3, 256, 256)
 
 
+def test_fp32_product_path_at_configs4_width_against_float64():
+    """the path `bench.py by_deg.hmc_latent` times -- configs/config_ffhq_latent.yml at full width in
+    fp32: LDM U-Net (fused GroupNorm glue, MIOpen convolutions), DDIM mixes, `k_vq_nearest`, VQ-f4 decoder, inpainting
+    data term -- against the SAME modules evaluated in float64 on the GPU (F64Product).  Continuous quantities (U-Net
+    output, the clipped decode that enters the quantiser) must agree to 1e-4.  The codebook lookup is discontinuous: a
+    latent pixel whose two nearest codes are closer than the fp32 network noise flips; the fraction of flipped codes is
+    reported and bounded, and loss / energy difference must sit inside the band that fraction explains (each flipped code
+    moves a 4 x 4 image patch by O(1): the loss moves by about its share of the pixels)."""
+    import nhmc.kernels as K
+    from nhmc import ldm, operators, sampler
+    dev = torch.device('cuda')
+    torch.manual_seed(3)
+    model = ldm.create_latent_model(ckpt=None, quiet=True).to(dev)
+    f64 = F64Product(model, dev)
+    gen = torch.Generator().manual_seed(6)
+    op = operators.Inpainting(3, 256, oops.random_inpaint_missing(256, generator=gen), dev)
+    B = 4
+    x = torch.randn(B, model.channels, 64, 64, generator=gen).to(dev)
+    p = torch.randn(B, model.channels, 64, 64, generator=gen).to(dev)
+    y = (torch.rand(B, op.M, generator=gen) * 2 - 1).to(dev)
+    t = torch.full((B,), 500.0, device=dev)
+    e32, e64 = model.apply_model(x, t), f64.apply_model(x, t)
+    err_unet = rel(e32, e64)
+    eng32, _ = _engine(model, op, dev)
+    eng64, _ = _engine(f64, op, dev)
+    z32, z64 = eng32.decode(x), eng64.decode(x)                      # 3 x (U-Net + DDIM mix) + final clip: what the quantiser sees
+    err_z = rel(z32, z64)
+    cb = model.first_stage_model.quantize.embedding.weight.detach().contiguous()
+    _, i32 = K.vq_nearest(z32.contiguous(), cb)
+    _, i64 = K.vq_nearest(z64.contiguous(), cb)
+    flipped = float((i32 != i64).float().mean())
+    st = sampler.ChainState(B, 1.0, 0.1, dev)
+    st['eps_eff'].fill_(0.1)
+    st['sigma_y'].fill_(0.5)
+    g32 = sampler.run_trajectory(eng32, x, p.clone(), y, st, 1.0, 2)
+    r32 = {k: g32[k].clone() for k in ('x_prop', 'xt', 'loss', 'H0', 'H1')}
+    g64 = sampler.run_trajectory(eng64, x, p.clone(), y, st, 1.0, 2)
+    err_loss = rel(r32['loss'], g64['loss'])
+    dH32, dH64 = (r32['H1'] - r32['H0']).cpu(), (g64['H1'] - g64['H0']).cpu()
+    k = 1 / (2 * 0.5 ** 2)
+    band = float(k * g64['loss'].max()) * (4 * flipped + 1e-4) + 1e-3 * float(g64['H1'].abs().max())
+    print(f'configs[4] width, fp32 vs float64 on the GPU: U-Net output {err_unet:.2e}, clipped decode {err_z:.2e}, flipped VQ codes '
+          f'{flipped:.2e} of {i32.numel()}, loss {err_loss:.2e}, |dH32 - dH64| max {float((dH32 - dH64).abs().max()):.3f} (band {band:.3f}), '
+          f'positions {rel(r32["x_prop"], g64["x_prop"]):.2e}')
+    assert err_unet < 1e-4 and err_z < 1e-4
+    assert flipped < 5e-3
+    assert err_loss < 4 * flipped + 1e-4
+    assert float((dH32 - dH64).abs().max()) < band
+
+
 def test_latent_cli_runs_the_reference_command_line(tmp_path, monkeypatch, capsys):
     """`main_sampling_latent.py`-compatible flags end to end (main_sampling_latent.py:791-918) on a small latent config
     written in the reference's yaml layout (configs/config_ffhq_latent.yml: target / params nesting)."""

@@ -153,19 +153,18 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
     assert whole and err < 1e-4
 
 
-@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso', 'color', 'cs4'])
-def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
-    """G16 (oracle/gen_golden_hmc_256.py): BASELINE configs[0] geometry -- 256 x 256, inpaint_random with 92 % of the
-    pixels missing, sigma_0 = 0.05, timesteps 3, tau 1.0, epsilon 0.05, one chain -- the reference's whole `hmc()` run
-    with the float64 tiny score, replayed through the kernels at the size the benchmark runs them; the same with
-    configs[2] / [3]'s operators (sr4; deblur_aniso = the reference instance G13 exported, on the MFMA pair kernels) and with
-    Colorization and WalshHadamardCS.
-    The seeded inputs are regenerated here in the generator's order; the 20 returned images are compared at 4096 probe
-    positions and by their norms."""
+# |dH - dH_ref| that the reference's own fp32 `torch.sum`s leave undetermined at 256 x 256, per operator: twice the largest
+# deviation measured on the MI355X over a whole run whose returned images are bit-identical (inpaint 0.125, sr4 0.047,
+# color 0.125, cs4 [grid score] see below; deblur_aniso 0.91: sigma_0 = 0.02 there, so the loss enters H with a factor
+# 1 / (2 sigma_y^2) = 1250 in the sampling phase and one fp32 ulp of the reference's loss sum is worth 0.01 .. 0.1 of H).
+E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 2.0, 'cs4': 1.0}
+MAX_FORCED = 24
+
+
+def _g16_problem(golden, deg, dim, dev):
     import nhmc.operators as ops
-    from nhmc import plugin, sampler
-    g = golden(f'g16_hmc_f64_{deg}_256.npz')
-    dim, dev = 256, torch.device('cuda')
+    name = f'g16b_hmc_grid_{deg}_256.npz' if deg == 'cs4' else f'g16_hmc_f64_{deg}_256.npz'
+    g = golden(name)
     if deg == 'inpaint':
         gm = torch.Generator().manual_seed(int(g['mask_seed']))
         r = 3 * torch.randperm(dim * dim, generator=gm)[: int(dim * dim * 0.92)].long()
@@ -196,20 +195,46 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
         U.append(float(torch.rand(1)))
     assert np.array_equal(np.array(U), g['u'])
     assert np.array_equal(P[0].reshape(-1)[:64].numpy(), g['p0_head']) and np.array_equal(P[-1].reshape(-1)[:64].numpy(), g['p_last_head'])
+    return g, op, x, x_orig, y_0, P
+
+
+@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso', 'color', 'cs4'])
+def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
+    """G16 (oracle/gen_golden_hmc_256.py): BASELINE configs[0] geometry -- 256 x 256, inpaint_random with 92 % of the
+    pixels missing, sigma_0 = 0.05, timesteps 3, tau 1.0, epsilon 0.05, one chain -- the reference's whole `hmc()` run
+    with the float64 tiny score, replayed through the kernels at the size the benchmark runs them; the same with
+    configs[2] / [3]'s operators (sr4; deblur_aniso = the reference instance G13 exported, on the MFMA pair kernels) and with
+    Colorization and WalshHadamardCS.  EVERY operator must make every accept decision of the reference's run and return
+    its 20 images (4096 probe positions and the norms) within north_star's 1e-4 -- measured: bit-identical for all five.
+
+    deblur_aniso: the MFMA products are exact k-ascending FMA chains like torch's CPU sgemm, the forward multiplies left
+    factor first and the adjoint right factor first as autograd does, so the data term is the reference's bits (round 2
+    ran the adjoint left-first and left the reference's run after 214 of 248 trajectories).
+    WalshHadamardCS: its fixture (g16b) was generated with oracle.tiny_score.GridF64Score instead of F64Score -- a float64
+    network still rounds differently on the CPU and on the GPU about 3 times per 1e9 outputs, and this operator's global
+    transform does not absorb such a flip as the local operators do (test below; tools/trace_replay.py).
+    The seeded inputs are regenerated here in the generator's order."""
+    from nhmc import plugin, sampler
+    from oracle.tiny_score import GridF64Score
+    dim, dev = 256, torch.device('cuda')
+    g, op, x, x_orig, y_0, P = _g16_problem(golden, deg, dim, dev)
+    n = len(g['u'])
     prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
     ref_acc = g['u'] < prob
     assert int(ref_acc.sum()) == 100
-    algo = plugin.HMC(F64Score(tiny_score).to(dev), op, float(g['sigma_0']))
+    score = GridF64Score(tiny_score, int(g['grid_bits'])) if 'grid_bits' in g else F64Score(tiny_score)
+    algo = plugin.HMC(score.to(dev), op, float(g['sigma_0']))
     opt = types.SimpleNamespace(tau=float(g['tau']), epsilon=float(g['epsilon']), m=float(g['m']), sigma_0=float(g['sigma_0']), quiet=True)
     # H is ~1e5 here (196 608 elements per term): one fp32 ulp of it is 0.0078 and the reference's own fp32 `torch.sum`s
     # carry several of them, so an accept decision whose log-uniform lies within E_TOL of -dH is not determined by the
     # algorithm.  Instead of a blanket band, only the decisions where the GPU's energies actually disagree are given to
     # the reference -- and only if they lie inside that tolerance: replay, and on the first differing decision check that
-    # it is such a one, force it, replay again.
-    E_TOL = 0.5
+    # it is such a one, force it, replay again.  At most MAX_FORCED decisions may be handed over that way.
+    E_TOL = E_TOL_256[deg]
     forced = set(np.nonzero(np.abs(g['u'] - prob) < BAND)[0].tolist())
+    n_band = len(forced)
     small = np.abs(g['neg_dH']) < 50
-    for attempt in range(24):
+    for attempt in range(MAX_FORCED + 1):
         idx = np.array(sorted(forced), dtype=np.int64)
         u_play = g['u'].astype(np.float32).copy()
         u_play[idx] = np.where(ref_acc[idx], 0.0, 1.0)
@@ -220,46 +245,85 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
         got_acc = np.array([bool(t['accept'][0]) for t in res.trace[:m]])
         got_dH = np.array([float(t['dH'][0]) for t in res.trace[:m]])
         wrong = np.nonzero(got_acc != ref_acc[:m])[0]
-        if deg == 'aniso' or not len(wrong):
+        if not len(wrong):
             break
         i = int(wrong[0])
         undetermined = abs(np.log(max(float(g['u'][i]), 1e-30)) - float(g['neg_dH'][i])) < E_TOL and abs(got_dH[i] + float(g['neg_dH'][i])) < E_TOL
         if not undetermined:
             break
         forced.add(i)
-    # energies: dH against the reference's where it is not astronomically large (a difference of two fp32 sums of ~1e5
-    # each on the reference's side: measured deviations reach 0.75 while every decision and the returned images agree)
     dev_dH = np.abs(got_dH + g['neg_dH'][:m])
-    off = (got_acc != ref_acc[:m]) | (small[:m] & (dev_dH > 2 * E_TOL))
+    off = (got_acc != ref_acc[:m]) | (small[:m] & (dev_dH > E_TOL))
     common = int(np.argmax(off)) if off.any() else m
     worst = float(np.max(dev_dH[:common][small[:common]])) if common else float('nan')
-    print(f'256 x 256 {deg}: {n} trajectories in the reference run, {len(forced)} decisions inside the energy tolerance given to the '
-          f'reference ({attempt + 1} replays), common prefix {common}, max |dH - dH_ref| on it {worst:.4f}')
+    print(f'256 x 256 {deg}: {n} trajectories in the reference run, {n_band} decisions inside the accept band + {len(forced) - n_band} inside '
+          f'the energy tolerance {E_TOL} given to the reference ({attempt + 1} replays), common prefix {common}, max |dH - dH_ref| on it {worst:.4f}')
     if common < m:
         print(f'   first departure at {common}: accept {got_acc[common]} vs {ref_acc[common]}, dH {got_dH[common]:.4f} vs {-g["neg_dH"][common]:.4f}, u {g["u"][common]:.4f}')
-    if deg == 'aniso':
-        # The MFMA products do not round as torch's CPU matmuls do, and at 196 608 elements per decode some value passes
-        # within that difference of the clip boundary sooner than at 32 x 32 (G14: all 191 trajectories): measured, the
-        # replay stays on the reference's run for 214 of its 248 trajectories (4 500 leapfrog steps, energies included),
-        # then one mask bit differs and the two runs are different realisations of the same chain.
-        assert common >= 200
-        return
-    if deg == 'cs4':
-        # The reference's run is followed for 198 trajectories (4 150 leapfrog steps: every decision, energy differences to
-        # 0.4); from there the energies drift (1.4 at trajectory 224) and at trajectory 226 a decision differs.  Somewhere a
-        # value differed in its last bit -- e.g. one of the ~7e9 float64 score outputs of this run rounding to another fp32
-        # neighbour on the GPU than on the CPU -- and this operator's global transform spreads that over the whole
-        # gradient, where the next clip-mask coincidence picks it up.  The 32 x 32 run (G15) is bit-identical to the end.
-        assert common >= 190
-        return
+    assert len(forced) <= MAX_FORCED
     assert not len(wrong) and res.iters == n                         # every accept decision of the reference's run
-    assert common == n
+    assert common == n                                                # ... and every energy difference inside the tolerance
     flat = res.samples[0].reshape(20, -1).cpu()
     pos = T(g['out_probe_pos']).long()
     err = float((flat[:, pos] - T(g['out_probe'])).abs().max() / float(g['out_absmax']))
     nerr = float((flat.double().norm(dim=1) - T(g['out_norm'])).abs().max() / T(g['out_norm']).max())
     print(f'returned images: probes rel err {err:.2e}, norms rel err {nerr:.2e}')
     assert err < 1e-4 and nerr < 1e-5
+
+
+def test_float64_stand_in_score_is_where_the_cs4_replay_left_the_reference(golden, tiny_score):
+    """Round 2's 256 x 256 WalshHadamardCS replay (fixture G16 cs4, float64 tiny score) followed the reference for 198 ..
+    224 trajectories "depending on the run".  With the reference's per-call checksum trace (G18,
+    oracle/gen_golden_checksums.py: every score input / output and every decode of the reference's run) the cause is
+    located: (i) two GPU replays are identical in every recorded quantity -- the prefix moved with the test's energy
+    threshold, not with the run; (ii) the first quantity that differs from the reference is a SCORE OUTPUT whose input was
+    the reference's bits: the float64 network itself (libm tanh, convolution order) rounds to the other fp32 neighbour,
+    about 3 times per 1e9 outputs; (iii) such flips are absorbed twice (a clipped pixel, a rounding) before one reaches
+    the decode, after which every gradient entry differs (the transform is global) -- trajectory 13 here; the energies
+    then drift apart over ~200 trajectories.  Up to that flip every kernel output recorded is the reference's bits.
+    The tail is still a valid realisation: all 100 epochs are accepted on the reference's decisions and the 20 returned
+    samples stay close to the reference's."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('trace_replay', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                               'tools', 'trace_replay.py'))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ref = dict(np.load(os.path.join(gold, 'g18_trace_cs4_256.npz'), allow_pickle=False))
+    got, g, n, res = tr.replay('cs4', None, gold, return_result=True)
+    L = 20
+    flips, first_in, last_clean = [], None, None
+    for it in range(n):
+        for j in range(1, L + 1):
+            rl, gl = it * (L + 1) + j, 1 + it * L + (j - 1)
+            for s_ in range(3):
+                same_in = got['score_in'][3 * gl + s_] == ref['score_in'][3 * rl + s_]
+                same_out = got['score_out'][3 * gl + s_] == ref['score_out'][3 * rl + s_]
+                if not same_in:
+                    first_in = (it, j, s_)
+                    break
+                if not same_out:
+                    flips.append((it, j, s_))
+            if first_in:
+                break
+            assert got['H_in'][gl] == ref['H_in'][rl] or flips and flips[-1][:2] == (it, j), (it, j)   # decodes: the reference's bits
+        if first_in:
+            break
+    print(f'cs4 at 256 x 256 against the reference trace: score-output flips on identical input before the runs separate: {flips}; '
+          f'first differing score INPUT at (trajectory, leapfrog step, DDIM step) {first_in}')
+    assert first_in is not None and first_in[0] >= 10                 # >= 10 trajectories = 200 ladders of bit-identical kernel outputs
+    assert flips and (first_in[0], first_in[1]) in {(flips[-1][0], flips[-1][1]), (flips[-1][0], flips[-1][1] + 1),
+                                                     (flips[-1][0] + 1, 1)}      # the separation starts AT a flip of the score
+    # the tail: a valid realisation near the reference's
+    assert res.iters == n and int(res.epoch[0]) == 100
+    flat = res.samples[0].reshape(20, -1).cpu()
+    g16 = golden('g16_hmc_f64_cs4_256.npz')
+    pos = T(g16['out_probe_pos']).long()
+    mean_dev = float((flat[:, pos].mean(0) - T(g16['out_probe']).mean(0)).abs().mean() / T(g16['out_probe']).mean(0).abs().mean())
+    nerr = float((flat.double().norm(dim=1) - T(g16['out_norm'])).abs().max() / T(g16['out_norm']).max())
+    print(f'   tail: sample-mean deviation at the probes {mean_dev:.3f} (relative), norms {nerr:.2e}')
+    assert mean_dev < 0.25 and nerr < 0.02
 
 
 def test_four_reference_runs_as_four_chains_of_one_call(golden, tiny_score):

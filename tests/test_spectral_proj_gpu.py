@@ -34,8 +34,8 @@ def test_projected_form_against_the_eight_products_and_float64(dim, B, sigma0):
     # a state next to the truth: |r| is at the noise level, where the missing U^T U cancellation weighs most; some
     # entries beyond [-1, 1] so the clip mask is exercised
     x = (1.02 * x0 + 0.05 * torch.randn(x0.shape, generator=g)).cuda().contiguous()
-    yy = y.reshape(x.shape).contiguous()
-    loss8, g8 = K.data_spectral(x, yy, op.factors, op.Dmap, True)
+    yT = y.reshape(x.shape).transpose(-1, -2).contiguous()                # the eight-product kernels take the planes transposed
+    loss8, g8 = K.data_spectral(x, yT, op.factors, op.Dmap, True, DmapT=op.DmapT)
     loss4, g4 = op.data_term(x, y, True)
     loss64, g64 = _f64_data_term(op, x, y)
     e8, e4 = _rel(g8, g64), _rel(g4, g64)
@@ -56,8 +56,8 @@ def test_projected_vjp_form_and_the_observation_cache():
     y = op.H(0.3 * K.randn_philox((B, 3, 256, 256), 5, 0, 2))
     at, an = torch.full((B,), 0.52, device='cuda'), torch.ones(B, device='cuda')
     nxt = K.ddim_mix_fwd(x, e, at, an, final_clip=True)['xt_next']
-    yy = y.reshape(x.shape).contiguous()
-    l8, gx8, ge8 = K.data_spectral_vjp(nxt, yy, op.factors, op.Dmap, x, e, at, an)
+    yT = y.reshape(x.shape).transpose(-1, -2).contiguous()
+    l8, gx8, ge8 = K.data_spectral_vjp(nxt, yT, op.factors, op.Dmap, x, e, at, an, DmapT=op.DmapT)
     l4, gx4, ge4 = op.fused_last_vjp(x, e, at, an, y, xt_next=nxt)
     assert _rel(l4, l8) < 1e-5 and _rel(gx4, gx8) < 3e-5 and _rel(ge4[:, :3], ge8[:, :3]) < 3e-5
     assert (ge4[:, 3:] == 0).all()
@@ -67,7 +67,8 @@ def test_projected_vjp_form_and_the_observation_cache():
     assert len(op._y_proj) == n0
     y.mul_(0.5)
     l4b, _, _ = op.fused_last_vjp(x, e, at, an, y, xt_next=nxt)
-    l8b, _, _ = K.data_spectral_vjp(nxt, y.reshape(x.shape).contiguous(), op.factors, op.Dmap, x, e, at, an)
+    l8b, _, _ = K.data_spectral_vjp(nxt, y.reshape(x.shape).transpose(-1, -2).contiguous(), op.factors, op.Dmap, x, e, at, an,
+                                    DmapT=op.DmapT)
     assert len(op._y_proj) == n0 + 1 and _rel(l4b, l8b) < 1e-5
 
 

@@ -8,6 +8,19 @@ import torch
 sys.path.insert(0, '.')
 import nhmc.kernels as K
 
+
+
+def chain_product(S1, x):
+    """S1^T x as an explicit k-ascending FMA chain from a zero accumulator, emulated in float64 on the GPU: a * b is
+    exact in float64 and fl32(a * b + acc) is the fused result (double rounding is possible in principle; none was
+    seen against torch's CPU sgemm in the build container, where the two agree bit for bit up to K = 256)."""
+    a, b = S1.double().cuda(), x.double().cuda()
+    acc = torch.zeros(x.shape[0], S1.shape[1], x.shape[2], dtype=torch.float32, device='cuda')
+    for k in range(S1.shape[0]):
+        acc = (a[k][None, :, None] * b[:, k][:, None, :] + acc.double()).float()
+    return acc.cpu()
+
+
 torch.manual_seed(0)
 for (n_img, K1, R1, C1) in ((6, 64, 64, 32), (6, 32, 32, 32), (3, 256, 256, 256), (6, 256, 256, 64), (6, 64, 256, 64)):
     x = torch.randn(n_img, K1, R1)
@@ -15,6 +28,9 @@ for (n_img, K1, R1, C1) in ((6, 64, 64, 32), (6, 32, 32, 32), (3, 256, 256, 256)
     eye = torch.eye(R1)
     want = torch.matmul(S1.t(), x)                                    # [n, C1, R1], torch CPU
     got = K.sandwich_rect(x.cuda(), S1.cuda(), eye.cuda()).cpu()      # (x^T S1)^T I = S1^T x
+    emu = chain_product(S1, x)
+    print(f'   MFMA product == emulated k-ascending FMA chain: {torch.equal(got, emu)} (mismatching {float((got != emu).float().mean()):.4f}); '
+          f'this host\'s torch CPU matmul == that chain: {torch.equal(want, emu)}')
     same = torch.equal(got, want)
     print(f'one product  K={K1} R={R1} C={C1}: bit-identical to torch CPU matmul: {same}; mismatching entries '
           f'{float((got != want).float().mean()):.4f}, max rel {float((got - want).abs().max() / want.abs().max()):.2e}')
