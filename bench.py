@@ -171,7 +171,9 @@ def kernel_table(device, prob, B, launches=40):
         ('k_mix_fwd (nhmc_ddim_mix_fwd)', 3 * T, lambda s: K.ddim_mix_fwd(s['x'], s['e'], at, an)),
         ('k_mix_bwd, two upstream gradients (nhmc_ddim_mix_bwd)', 6 * T,
          lambda s: K.ddim_mix_bwd(s['g'], s['x'], s['e'], at, an, gout2=s['g2'], g_e_out=s['ge'])),
-        ('data term + last-step VJP fused (operator.fused_last_vjp; incl. the 4 us partial-sum kernel)', 4 * T + int(op.M) * 4 * B,
+        ('data term + last-step VJP fused, as a MID step launches it (operator.fused_last_vjp, loss partials not summed)',
+         4 * T + int(op.M) * 4 * B, lambda s: op.fused_last_vjp(s['x'], s['e'], an, one, y, g_e_out=s['ge'], loss_out=K.NO_LOSS)),
+        ('the same with the per-chain loss (first / last step of a trajectory: + the partial-sum kernel)', 4 * T + int(op.M) * 4 * B,
          lambda s: op.fused_last_vjp(s['x'], s['e'], an, one, y, g_e_out=s['ge'])),
         ('k_leapfrog<MID>, second gradient pointer (nhmc_leapfrog_fused)', 6 * T,
          lambda s: K.leapfrog_fused(K.LF_MID, s['x'], s['p'], s['g'], eps, sig, 1.0, g2=s['g2'])),
@@ -251,8 +253,8 @@ def data_term_roofline(device, prob, B, launches=30):
     xt_next = K.ddim_mix_fwd(x, e, at, atn, final_clip=True)['xt_next']
     extra = dict(xt_next=xt_next) if getattr(op, 'fused_wants_decode', False) else {}
 
-    def call():
-        return op.fused_last_vjp(x, e, at, atn, y, g_e_out=ge, **extra)
+    def call():                                                # as a MID leapfrog step launches it: gradient only, no loss summation
+        return op.fused_last_vjp(x, e, at, atn, y, g_e_out=ge, loss_out=K.NO_LOSS, **extra)
     for _ in range(3):
         call()
     torch.cuda.synchronize()

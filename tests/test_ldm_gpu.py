@@ -295,7 +295,7 @@ def test_fp32_product_path_at_configs4_width_against_float64():
     err_loss = rel(r32['loss'], g64['loss'])
     dH32, dH64 = (r32['H1'] - r32['H0']).cpu(), (g64['H1'] - g64['H0']).cpu()
     k = 1 / (2 * 0.5 ** 2)
-    band = float(k * g64['loss'].max()) * (4 * flipped + 1e-4) + 1e-3 * float(g64['H1'].abs().max())
+    band = float(k * g64['loss'].max()) * (4 * flipped + 1e-5) + 2e-5 * float(g64['H1'].abs().max())
     print(f'configs[4] width, fp32 vs float64 on the GPU: U-Net output {err_unet:.2e}, clipped decode {err_z:.2e}, flipped VQ codes '
           f'{flipped:.2e} of {i32.numel()}, loss {err_loss:.2e}, |dH32 - dH64| max {float((dH32 - dH64).abs().max()):.3f} (band {band:.3f}), '
           f'positions {rel(r32["x_prop"], g64["x_prop"]):.2e}')

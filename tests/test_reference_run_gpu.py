@@ -163,7 +163,7 @@ MAX_FORCED = 24
 
 def _g16_problem(golden, deg, dim, dev):
     import nhmc.operators as ops
-    name = f'g16b_hmc_grid_{deg}_256.npz' if deg == 'cs4' else f'g16_hmc_f64_{deg}_256.npz'
+    name = f'g16b_hmc_grid_{deg}_256.npz' if deg in ('cs4', 'aniso') else f'g16_hmc_f64_{deg}_256.npz'      # global operators: grid score
     g = golden(name)
     if deg == 'inpaint':
         gm = torch.Generator().manual_seed(int(g['mask_seed']))
@@ -210,9 +210,12 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     deblur_aniso: the MFMA products are exact k-ascending FMA chains like torch's CPU sgemm, the forward multiplies left
     factor first and the adjoint right factor first as autograd does, so the data term is the reference's bits (round 2
     ran the adjoint left-first and left the reference's run after 214 of 248 trajectories).
-    WalshHadamardCS: its fixture (g16b) was generated with oracle.tiny_score.GridF64Score instead of F64Score -- a float64
-    network still rounds differently on the CPU and on the GPU about 3 times per 1e9 outputs, and this operator's global
-    transform does not absorb such a flip as the local operators do (test below; tools/trace_replay.py).
+    The two GLOBAL operators (deblur_aniso: dense 256 x 256 factors; WalshHadamardCS) take their fixtures (g16b) from the
+    same reference run with oracle.tiny_score.GridF64Score instead of F64Score: a float64 network still rounds differently
+    on the CPU and on the GPU about 3 times per 1e9 outputs, and a transform that mixes every pixel into every gradient
+    entry does not absorb such a flip as the local operators do (test below; tools/trace_replay.py) -- with the plain
+    float64 score the aniso replay makes all 248 decisions of the reference's run but returns images 5e-3 away, the cs4
+    replay leaves the reference's run at trajectory 13.
     The seeded inputs are regenerated here in the generator's order."""
     from nhmc import plugin, sampler
     from oracle.tiny_score import GridF64Score

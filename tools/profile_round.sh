@@ -5,7 +5,7 @@ set -x
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_r${ROUND:-02}
 mkdir -p $OUT
-NHMC_PROFILE_MARK=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-by-deg > $OUT/e2e_bench.json 2> $OUT/e2e.err
+NHMC_PROFILE_MARK=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-by-deg --no-full-run > $OUT/e2e_bench.json 2> $OUT/e2e.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kern -- python3 bench.py --kernel-only --no-cpu-baseline > $OUT/kern_bench.json 2> $OUT/kern.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --kernel-only --no-cpu-baseline --roofline-launches 24 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --kernel-only --no-cpu-baseline --roofline-launches 24 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
