@@ -595,9 +595,8 @@ extern "C" int nhmc_ddim_mix_bwd_inpaint_px(const float* xt, const float* e, int
 }
 
 extern "C" int nhmc_sr_vjp_tiles(int channels, int dim, int ratio) {
-  const int waves_form = ratio == 4 ? channels * (((dim / 4) * (dim / 4) + NHMC_WAVE - 1) / NHMC_WAVE) : 0;
-  const int rows_form = nhmc_sr_tiles(channels, dim, ratio);
-  return waves_form > rows_form ? waves_form : rows_form;             // room for either form of the ratio-4 kernel
+  if (ratio == 4 && channels <= 65535) return channels * (((dim / 4) * (dim / 4) + NHMC_WAVE - 1) / NHMC_WAVE);
+  return nhmc_sr_tiles(channels, dim, ratio);
 }
 
 extern "C" int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_channels, const float* at,
@@ -607,8 +606,7 @@ extern "C" int nhmc_ddim_mix_bwd_sr(const float* xt, const float* e, int e_chann
   if (dim <= 0 || (dim % 4) || bad_shape(n_chains, channels, (int64_t)dim * dim, e_channels)) return NHMC_ERR_SHAPE;
   if (!(ratio == 2 || ratio == 4 || ratio == 8 || ratio == 16) || (dim % ratio)) return NHMC_ERR_SHAPE;
   if (!nhmc_aligned16(xt) || !nhmc_aligned16(e) || !nhmc_aligned16(g_xt) || !nhmc_aligned16(g_e)) return NHMC_ERR_ALIGN;
-  static const bool sr4_waves = [] { const char* v = getenv("NHMC_SR4_FORM"); return !(v && v[0] == 'r'); }();   // A/B switch: "rows" = the generic form
-  if (ratio == 4 && channels <= 65535 && sr4_waves) {
+  if (ratio == 4 && channels <= 65535) {
     const int per_plane = ((dim / 4) * (dim / 4) + NHMC_WAVE - 1) / NHMC_WAVE;
     NHMC_LAUNCH(k_mix_bwd_sr4, dim3((unsigned)per_plane, (unsigned)channels, (unsigned)n_chains), dim3(NHMC_BLOCK), 0,
                 nhmc_s(stream), (const float4*)xt, (const float4*)e, e_channels, at, at_next, y, (float4*)g_xt,

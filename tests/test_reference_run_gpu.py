@@ -154,10 +154,9 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
 
 
 # |dH - dH_ref| that the reference's own fp32 `torch.sum`s leave undetermined at 256 x 256, per operator: twice the largest
-# deviation measured on the MI355X over a whole run whose returned images are bit-identical (inpaint 0.125, sr4 0.047,
-# color 0.125, cs4 [grid score] see below; deblur_aniso 0.91: sigma_0 = 0.02 there, so the loss enters H with a factor
-# 1 / (2 sigma_y^2) = 1250 in the sampling phase and one fp32 ulp of the reference's loss sum is worth 0.01 .. 0.1 of H).
-E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 2.0, 'cs4': 1.0}
+# deviation measured on the MI355X over the whole run (whose returned images are bit-identical): inpaint 0.125, sr4 0.047,
+# color 0.125, deblur_aniso 0.125, cs4 0.5 (H is ~1e5 in fp32: one ulp is 0.0078 and a sum of 196 608 terms carries several).
+E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0}
 MAX_FORCED = 24
 
 
