@@ -556,7 +556,7 @@ def hmc(x, n, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig):
 # diagonal-mass variant
 # --------------------------------------------------------------------------------------------- #
 def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *, noise=None, burn=5, epochs=40,
-                    sampling=10, chunk=None, max_iters=None, collect_trace=False, mass_tables=None):
+                    sampling=10, chunk=None, max_iters=None, collect_trace=False, mass_tables=None, reuse=True):
     """Per-chain form of `hmc_test_conditioning` (main_sampling.py:776-894): HMC with a diagonal mass rebuilt from
     the rank transform of each accepted trajectory's position variance.  Returns SimpleNamespace(samples
     [B, 4*sampling-sampling... = total-(epochs+sampling), C, H, W], x, epoch, n_accept, n_reject, iters, trace)."""
@@ -586,13 +586,22 @@ def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *
     # mass_tables = (std, inv) overrides them (a parity test hands in the tables of the host the reference ran on).
     tables = tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in mass_tables) if mass_tables is not None \
         else _mass_tables(N, device)
+    # (loss, summed gradient) at the accepted position, slot 0 of a GradCache whose selector stays 0: :823-825 re-evaluates a
+    # point the previous iteration already evaluated (see GradCache); slot 1 takes the end point of every trajectory and
+    # is copied over slot 0 for the chains that accept
+    cache = GradCache(x) if reuse else None
     trace = [] if collect_trace else None
     it = 0
     while True:
         K.schedule_begin_mass(st, sigma_table, burn, epochs, sampling)
         z = noise.momentum(it, x, 1.0)
         eps, sy, won = st['eps_eff'], st['sigma_y'], st['welford_on']
-        xt, loss, ga, gb = engine.decode_and_grad(x, y_0)
+        if cache is None:
+            xt, loss, ga, gb = engine.decode_and_grad(x, y_0)
+        else:
+            if not cache.valid:
+                engine.prime(cache, x, y_0)
+            loss, ga, gb = cache.loss[0], cache.g[0], None
         x_prop, p = x.clone(), torch.empty_like(x)
         m2.zero_()                                      # chains without Welford keep M2 = 0 (the reference's zeros, :802)
         K.leapfrog_mass(K.LF_FIRST, x_prop, p, ga, inv_m, eps, sy, ws, g2=gb, z=z, std_m=std_m)
@@ -604,6 +613,10 @@ def hmc_mass_chains(x, b, seq, seq_next, algo, opt, y_0, H_funcs, x_orig=None, *
         H1 = K.hamiltonian(ws, N, loss, sy, 1.0)
         u = noise.uniform(it, B, device)
         accept, dH = K.metropolis(H0, H1, u, st['active'])
+        if cache is not None:
+            K.grad_cache_store(ga, gb, loss, cache.g, cache.loss, cache.sel, flip=1)          # end point -> slot 1
+            K.accept_commit(accept, st['epoch'], cache.g[0], cache.g[1], None, None, 0, 0)    # accepted chains: slot 1 -> slot 0
+            cache.loss[0].copy_(torch.where(accept.bool(), cache.loss[1], cache.loss[0]))
         # mass rebuild for accepted chains past epochs//3 (pre-increment epoch, :857)
         flags = (accept * (st['epoch'] > epochs // 3).int()).contiguous()
         sort_ws = K.mass_from_variance(m2, L, flags, inv_m, std_m, tables, sort_ws)

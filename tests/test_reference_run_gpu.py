@@ -156,13 +156,14 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
 # |dH - dH_ref| that the reference's own fp32 `torch.sum`s leave undetermined at 256 x 256, per operator: twice the largest
 # deviation measured on the MI355X over the whole run (whose returned images are bit-identical): inpaint 0.125, sr4 0.047,
 # color 0.125, deblur_aniso 0.125, cs4 0.5 (H is ~1e5 in fp32: one ulp is 0.0078 and a sum of 196 608 terms carries several).
-E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0}
+E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 1.0, 'bicubic4': 1.0}
+GRID_SCORE_256 = ('cs4', 'aniso', 'gauss', 'bicubic4')               # global operators: fixtures g16b (grid score)
 MAX_FORCED = 24
 
 
 def _g16_problem(golden, deg, dim, dev):
     import nhmc.operators as ops
-    name = f'g16b_hmc_grid_{deg}_256.npz' if deg in ('cs4', 'aniso') else f'g16_hmc_f64_{deg}_256.npz'      # global operators: grid score
+    name = f'g16b_hmc_grid_{deg}_256.npz' if deg in GRID_SCORE_256 else f'g16_hmc_f64_{deg}_256.npz'
     g = golden(name)
     if deg == 'inpaint':
         gm = torch.Generator().manual_seed(int(g['mask_seed']))
@@ -176,6 +177,10 @@ def _g16_problem(golden, deg, dim, dev):
         op = ops.Colorization(dim, dev)
     elif deg == 'cs4':                                                 # the d = 256 register fast path of the FWHT passes
         op = ops.WalshHadamardCS(3, dim, 4, torch.randperm(dim * dim, generator=torch.Generator().manual_seed(1600)), dev)
+    elif deg == 'gauss':                                               # the reference instance's own factors (as G15)
+        op = ops.Deblurring2D.from_factors(T(g['gauss_U']), T(g['gauss_U']), T(g['gauss_V']), T(g['gauss_V']), T(g['gauss_D']), dev)
+    elif deg == 'bicubic4':
+        op = ops.SRConv.from_svd(T(g['srconv_U']), T(g['srconv_s']), T(g['srconv_V']), 3, dim, dev, stride=int(g['factor']))
     else:
         a = golden('g13_aniso_256.npz')
         D = oops.SpectralBlurRef.multiplier_map(T(a['s_sorted']), T(a['perm'].astype(np.int64)), 3, dim)
@@ -197,7 +202,7 @@ def _g16_problem(golden, deg, dim, dev):
     return g, op, x, x_orig, y_0, P
 
 
-@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso', 'color', 'cs4'])
+@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso', 'color', 'cs4', 'gauss', 'bicubic4'])
 def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     """G16 (oracle/gen_golden_hmc_256.py): BASELINE configs[0] geometry -- 256 x 256, inpaint_random with 92 % of the
     pixels missing, sigma_0 = 0.05, timesteps 3, tau 1.0, epsilon 0.05, one chain -- the reference's whole `hmc()` run
@@ -216,9 +221,13 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     float64 score the aniso replay makes all 248 decisions of the reference's run but returns images 5e-3 away, the cs4
     replay leaves the reference's run at trajectory 13.
     The seeded inputs are regenerated here in the generator's order."""
+    import os
     from nhmc import plugin, sampler
     from oracle.tiny_score import GridF64Score
+    from tests.conftest import GOLDEN
     dim, dev = 256, torch.device('cuda')
+    if deg in ('gauss', 'bicubic4') and not os.path.exists(os.path.join(GOLDEN, f'g16b_hmc_grid_{deg}_256.npz')):
+        pytest.skip('fixture not generated (oracle/gen_golden_hmc_256.py %s grid: ~1 h of the reference on 8 cores)' % deg)
     g, op, x, x_orig, y_0, P = _g16_problem(golden, deg, dim, dev)
     n = len(g['u'])
     prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
