@@ -156,7 +156,7 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
 # |dH - dH_ref| that the reference's own fp32 `torch.sum`s leave undetermined at 256 x 256, per operator: twice the largest
 # deviation measured on the MI355X over the whole run (whose returned images are bit-identical): inpaint 0.125, sr4 0.047,
 # color 0.125, deblur_aniso 0.125, cs4 0.5 (H is ~1e5 in fp32: one ulp is 0.0078 and a sum of 196 608 terms carries several).
-E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 1.0, 'bicubic4': 0.125}
+E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 1.0, 'bicubic4': 0.125, 'sr16': 0.5, 'box': 0.5}
 GRID_SCORE_256 = ('cs4', 'aniso', 'gauss', 'bicubic4')               # global operators: fixtures g16b (grid score)
 MAX_FORCED = 24
 
@@ -173,6 +173,14 @@ def _g16_problem(golden, deg, dim, dev):
         op = ops.Inpainting(3, dim, missing, dev)
     elif deg == 'sr4':
         op = ops.SuperResolution(3, dim, 4, dev)
+    elif deg == 'sr16':
+        op = ops.SuperResolution(3, dim, 16, dev)
+    elif deg == 'box':                                                 # inpaint_box with the 128 x 128 box at (64, 64)
+        m3 = torch.zeros(dim, dim, 3)
+        m3[64:192, 64:192, :] = 1.0
+        missing = torch.nonzero(m3.view(-1)).squeeze(1)
+        assert int(missing.sum()) == int(g['missing_sum'])
+        op = ops.Inpainting(3, dim, missing, dev)
     elif deg == 'color':
         op = ops.Colorization(dim, dev)
     elif deg == 'cs4':                                                 # the d = 256 register fast path of the FWHT passes
@@ -202,7 +210,7 @@ def _g16_problem(golden, deg, dim, dev):
     return g, op, x, x_orig, y_0, P
 
 
-@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso', 'color', 'cs4', 'gauss', 'bicubic4'])
+@pytest.mark.parametrize('deg', ['inpaint', 'sr4', 'aniso', 'color', 'cs4', 'gauss', 'bicubic4', 'sr16', 'box'])
 def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     """G16 (oracle/gen_golden_hmc_256.py): BASELINE configs[0] geometry -- 256 x 256, inpaint_random with 92 % of the
     pixels missing, sigma_0 = 0.05, timesteps 3, tau 1.0, epsilon 0.05, one chain -- the reference's whole `hmc()` run
@@ -226,8 +234,9 @@ def test_whole_reference_run_at_baseline_image_size(golden, tiny_score, deg):
     from oracle.tiny_score import GridF64Score
     from tests.conftest import GOLDEN
     dim, dev = 256, torch.device('cuda')
-    if deg in ('gauss', 'bicubic4') and not os.path.exists(os.path.join(GOLDEN, f'g16b_hmc_grid_{deg}_256.npz')):
-        pytest.skip('fixture not generated (oracle/gen_golden_hmc_256.py %s grid: ~1 h of the reference on 8 cores)' % deg)
+    fixture = f'g16b_hmc_grid_{deg}_256.npz' if deg in GRID_SCORE_256 else f'g16_hmc_f64_{deg}_256.npz'
+    if not os.path.exists(os.path.join(GOLDEN, fixture)):
+        pytest.skip(f'{fixture} not generated (oracle/gen_golden_hmc_256.py {deg}: 0.5 - 1 h of the reference on 8 cores)')
     g, op, x, x_orig, y_0, P = _g16_problem(golden, deg, dim, dev)
     n = len(g['u'])
     prob = np.minimum(1.0, np.exp(np.minimum(g['neg_dH'], 50.0)))
