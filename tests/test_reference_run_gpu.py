@@ -156,7 +156,7 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
 # |dH - dH_ref| that the reference's own fp32 `torch.sum`s leave undetermined at 256 x 256, per operator: twice the largest
 # deviation measured on the MI355X over the whole run (whose returned images are bit-identical): inpaint 0.125, sr4 0.047,
 # color 0.125, deblur_aniso 0.125, cs4 0.5 (H is ~1e5 in fp32: one ulp is 0.0078 and a sum of 196 608 terms carries several).
-E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 1.0, 'bicubic4': 0.125, 'sr16': 0.5, 'box': 0.5}
+E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 0.25, 'bicubic4': 0.125, 'sr16': 0.5, 'box': 0.5}
 GRID_SCORE_256 = ('cs4', 'aniso', 'gauss', 'bicubic4')               # global operators: fixtures g16b (grid score)
 MAX_FORCED = 24
 
