@@ -131,9 +131,24 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_sr(
   float bs[BPS];
 #pragma unroll
   for (int b = 0; b < BPS; ++b) bs[b] = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) rows[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) rows[rr] = nhmc_ldnt(&xt[row0 + (int64_t)rr * w4]);
+  }
+  if constexpr (LANES > 1) {                    // R >= 8: the block spans LANES strips -- row-major running sum across them
+    float4 vals[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      vals[rr] = rows[rr];
+      if (MODE == 0 && apply_clip) {
+        vals[rr].x = nhmc_clip1(vals[rr].x); vals[rr].y = nhmc_clip1(vals[rr].y);
+        vals[rr].z = nhmc_clip1(vals[rr].z); vals[rr].w = nhmc_clip1(vals[rr].w);
+      }
+    }
+    bs[0] = nhmc_block_sum_rowmajor<R, LANES>(vals, s % LANES);
+  } else if (live) {
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       const float* e = reinterpret_cast<const float*>(&rows[rr]);
@@ -143,10 +158,6 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_sr(
         bs[BPS == 1 ? 0 : c / R] += v;
       }
     }
-  }
-  if (LANES > 1) {                              // combine the R/4 strips of a block (adjacent lanes)
-#pragma unroll
-    for (int off = 1; off < LANES; off <<= 1) bs[0] += __shfl_xor(bs[0], off, NHMC_WAVE);
   }
   if (!live) { /* fallthrough to the reduction with acc = 0 */ }
   float resid[BPS];

@@ -351,27 +351,32 @@ __global__ __launch_bounds__(NHMC_BLOCK) void k_mix_bwd_sr(
   }
   unsigned in_pre = 0u, in_u = 0u;              // bit rr*4+c: 1[-1 <= pre <= 1], 1[-1 <= u <= 1]   (R <= 8 rows per word)
   unsigned in_pre_hi = 0u, in_u_hi = 0u;        // rows 8..15 (R = 16)
+  float4 dec[LANES > 1 ? R : 1];                // R >= 8: the clipped decodes, for the row-major sum across the strips
+  if constexpr (LANES > 1) {
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) dec[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (live) {
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
       const float4 xv = nhmc_ldnt(&xt[xrow0 + (int64_t)rr * w4]), ev = nhmc_ldnt(&e[erow0 + (int64_t)rr * w4]);
       const float* xe = reinterpret_cast<const float*>(&xv);
       const float* ee = reinterpret_cast<const float*>(&ev);
+      float cl[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float u = (xe[c] - ee[c] * k.c1) / k.c2;
         const float pre = k.c3 * nhmc_clip1(u) + k.c4 * ee[c];
-        bs[BPS == 1 ? 0 : c / R] += nhmc_clip1(pre);
+        cl[c] = nhmc_clip1(pre);
+        if (LANES == 1) bs[BPS == 1 ? 0 : c / R] += cl[c];
         const unsigned bit = 1u << (((rr & 7) << 2) + c);
         if (rr < 8) { if (pre >= -1.0f && pre <= 1.0f) in_pre |= bit; if (u >= -1.0f && u <= 1.0f) in_u |= bit; }
         else        { if (pre >= -1.0f && pre <= 1.0f) in_pre_hi |= bit; if (u >= -1.0f && u <= 1.0f) in_u_hi |= bit; }
       }
+      if constexpr (LANES > 1) dec[rr] = make_float4(cl[0], cl[1], cl[2], cl[3]);
     }
   }
-  if (LANES > 1) {
-#pragma unroll
-    for (int off = 1; off < LANES; off <<= 1) bs[0] += __shfl_xor(bs[0], off, NHMC_WAVE);
-  }
+  if constexpr (LANES > 1) bs[0] = nhmc_block_sum_rowmajor<R, LANES>(dec, s % LANES);   // the reference's order (nhmc_common.h)
   float acc = 0.0f, resid[BPS];
 #pragma unroll
   for (int b = 0; b < BPS; ++b) {

@@ -48,6 +48,30 @@ __device__ __forceinline__ void nhmc_block_sum(double (&v)[NV], double* lds /* [
   }
 }
 
+// Sum of an R x R block of pixels held as R float4 strips per lane by LANES = R / 4 adjacent, LANES-aligned lanes of a
+// wave, in the REFERENCE'S ORDER: row by row, left to right, one running fp32 sum (SuperResolution.H is a matmul of the
+// unfolded patch -- index kh * R + kw -- with a column of +-1/R, Hfuncs.py:188-200: a k-ascending FMA chain with a power-
+// of-two weight, i.e. exactly this sequential sum times 1/R^2; so is avg_pool2d).  The running sum is handed from lane to
+// lane with shuffles: R * LANES steps.  A pairwise tree over the lanes (round 2) adds the same numbers in another order
+// and was 1e-7 off per evaluation, 4.7e-6 after a whole sr16 run.  Returns the block sum in every lane of the group.
+template <int R, int LANES>
+__device__ __forceinline__ float nhmc_block_sum_rowmajor(const float4 (&v)[R], int lane_in_group) {
+  const int lane = threadIdx.x & (NHMC_WAVE - 1), base = lane - lane_in_group;
+  float acc = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+    for (int ln = 0; ln < LANES; ++ln) {
+      const float prev = __shfl(acc, base + (ln == 0 ? LANES - 1 : ln - 1), NHMC_WAVE);
+      if (lane_in_group == ln) {
+        acc = (rr == 0 && ln == 0) ? 0.0f : prev;
+        acc += v[rr].x; acc += v[rr].y; acc += v[rr].z; acc += v[rr].w;
+      }
+    }
+  }
+  return __shfl(acc, base + LANES - 1, NHMC_WAVE);
+}
+
 // Streaming (non-temporal) 16-byte accesses: every image element on this path is touched once per kernel, so
 // loads and stores carry the nt hint (measured on MI355X, fused update at B = 64: 49.5 -> 41.8 us).
 typedef float nhmc_v4f __attribute__((ext_vector_type(4)));

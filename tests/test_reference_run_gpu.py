@@ -95,8 +95,9 @@ def test_whole_reference_run_on_the_gpu(golden, tiny_score, deg):
 # mean reproduce torch's bits -- with the collapsed colour weights the replay left the reference's run after 62
 # trajectories, with an ascending adjoint after 183; the bicubic operator applies V^T, the singular values and U in turn
 # as rounded stages (eight MFMA products per data term; round 2's collapsed A X A^T form reproduced the decisions but
-# left the images at 1.3e-4 .. 4.3e-4).  Measured on the MI355X: box, color, cs4 return bit-identical images, sr16 4.7e-6,
-# deblur_gauss (MFMA chain) 6.4e-6; every operator is held to north_star's 1e-4.
+# left the images at 1.3e-4 .. 4.3e-4); the x16 block mean adds its 256 pixels in the reference's row-major order (a running
+# sum handed from lane to lane; round 2's pairwise tree over the lanes left sr16 at 4.7e-6).  Measured on the MI355X: ALL SIX
+# return bit-identical images (with G14's three: all nine operators); every operator is held to north_star's 1e-4.
 
 
 def _g15_operator(g, deg, dim, dev):
@@ -156,8 +157,8 @@ def test_reference_runs_of_the_remaining_operators(golden, tiny_score, deg, dim)
 # |dH - dH_ref| that the reference's own fp32 `torch.sum`s leave undetermined at 256 x 256, per operator: twice the largest
 # deviation measured on the MI355X over the whole run (whose returned images are bit-identical): inpaint 0.125, sr4 0.047,
 # color 0.125, deblur_aniso 0.125, cs4 0.5 (H is ~1e5 in fp32: one ulp is 0.0078 and a sum of 196 608 terms carries several).
-E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 0.25, 'bicubic4': 0.125, 'sr16': 0.5, 'box': 0.5}
-GRID_SCORE_256 = ('cs4', 'aniso', 'gauss', 'bicubic4')               # global operators: fixtures g16b (grid score)
+E_TOL_256 = {'inpaint': 0.25, 'sr4': 0.1, 'color': 0.25, 'aniso': 0.25, 'cs4': 1.0, 'gauss': 0.25, 'bicubic4': 0.125, 'sr16': 0.1, 'box': 0.5}
+GRID_SCORE_256 = ('cs4', 'aniso', 'gauss', 'bicubic4', 'box')       # fixtures g16b (grid score): the global operators, and the box mask (75 % observed: too few masked pixels to absorb a flip)
 MAX_FORCED = 24
 
 
