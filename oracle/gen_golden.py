@@ -161,7 +161,7 @@ def g3_ddim(ms, dim=32):
     save(f'g3_ddim_{dim}.npz', x=np32(x), w=np32(w), xt=np32(xt), grad=np32(grad))
 
 
-def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=None, probe=0, grid_bits=0):
+def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=None, probe=0, grid_bits=0, grid_absolute=False):
     """f64=True -> g14_hmc_f64_*: the same reference run with the tiny score evaluated in float64 (oracle.tiny_score.F64Score,
     the model is hmc()'s argument); stores every uniform and -dH so a GPU test can replay the whole run on the same tape.
     op / out_name / extra: another reference operator object, the fixture's file name and its operator data
@@ -177,7 +177,7 @@ def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=
     net = tiny_model()
     if f64 and grid_bits:                                     # oracle.tiny_score.GridF64Score: reproducible across devices (g16b)
         from oracle.tiny_score import GridF64Score
-        net = GridF64Score(net, grid_bits)
+        net = GridF64Score(net, grid_bits, absolute=grid_absolute)
     elif f64:
         from oracle.tiny_score import F64Score
         net = F64Score(net)
@@ -256,6 +256,7 @@ def g4_hmc(ms, deg, dim=32, seed=5678, f64=False, op=None, out_name=None, extra=
     arrays.update(extra or {})
     if grid_bits:
         arrays['grid_bits'] = np.array(grid_bits)
+        arrays['grid_absolute'] = np.array(int(grid_absolute))
     save(out_name or (f'g14_hmc_f64_{deg}_{dim}.npz' if f64 else f'g4_hmc_{deg}_{dim}.npz'), **arrays)
     print(f'   {deg}: {len(rec["u"])} iterations, {len(psnr)} accepts, final PSNR {psnr[-1]:.3f}')
 

@@ -60,19 +60,29 @@ def round_bits(t, bits):
     return torch.ldexp(torch.round(torch.ldexp(m, torch.full_like(e, bits))), e - bits)
 
 
+def round_grid(t, bits):
+    """float64 tensor -> the nearest multiple of q = 2^(e - bits), 2^e the power of two just above max |t| (ties to even).
+    An ABSOLUTE grid per tensor: an entry that is small because its terms cancel (where the CPU's and the GPU's float64
+    results differ by far more than 1e-16 of the entry) is rounded as coarsely as the large ones, which `round_bits`
+    (a relative grid per entry) does not do.  Exact operations; values stay exact in fp32 for bits <= 24."""
+    _, e = torch.frexp(t.abs().max())
+    q = torch.ldexp(torch.ones((), dtype=t.dtype, device=t.device), e - bits)
+    return torch.round(t / q) * q
+
+
 class _GridNet(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, t, net, bits):
+    def forward(ctx, x, t, net, bits, absolute):
         with torch.enable_grad():
             xd = x.detach().double().requires_grad_(True)
             out = net(xd, t.double())
-        ctx.xd, ctx.out, ctx.bits = xd, out, bits
-        return round_bits(out.detach(), bits).float()
+        ctx.xd, ctx.out, ctx.bits, ctx.absolute = xd, out, bits, absolute
+        return (round_grid if absolute else round_bits)(out.detach(), bits).float()
 
     @staticmethod
     def backward(ctx, g):
         (gin,) = torch.autograd.grad(ctx.out, ctx.xd, g.double())
-        return round_bits(gin, ctx.bits).float(), None, None, None
+        return (round_grid if ctx.absolute else round_bits)(gin, ctx.bits).float(), None, None, None, None
 
 
 class GridF64Score(nn.Module):
@@ -86,10 +96,13 @@ class GridF64Score(nn.Module):
     flip needs the float64 value within ~1e-16 of a midpoint of a 2^-bits grid, 2^(24 - bits) times rarer (bits = 10:
     once in ~1e12 values, ~0.03 expected per whole run).  Still an ARGUMENT of the reference's `hmc()`."""
 
-    def __init__(self, net, bits=10):
+    def __init__(self, net, bits=10, absolute=False):
+        """absolute: round on one absolute grid per tensor (`round_grid`, bits below the tensor's largest magnitude)
+        instead of per-entry significant bits -- for problems whose input gradient has entries that are small by
+        cancellation (the box mask: the gradient vanishes inside the box)."""
         super().__init__()
         import copy
-        self.net, self.bits = copy.deepcopy(net).double(), bits
+        self.net, self.bits, self.absolute = copy.deepcopy(net).double(), bits, bool(absolute)
 
     def forward(self, x, t):
-        return _GridNet.apply(x, t, self.net, self.bits)
+        return _GridNet.apply(x, t, self.net, self.bits, self.absolute)
