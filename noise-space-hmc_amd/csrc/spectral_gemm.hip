@@ -238,6 +238,15 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 // So the pair form does not beat the chain on time -- each block still serialises ~16 us of slab staging, barriers and
 // the 64 KB epilogue against 27 us of MFMA work, and one block fits a CU -- but it halves the launches and keeps
 // half of the intermediates (8T of 16T per chain) out of HBM.
+// NHMC_PAIR_STAMPS (tools/pair_stamps.hip only; never defined in the product build): thread 0 of every workgroup records
+// clock64() at the phase boundaries, for the per-phase attribution in profiles/.
+#ifdef NHMC_PAIR_STAMPS
+__device__ long long* nhmc_pair_stamps = nullptr;               // [workgroup][8]
+#define NHMC_STAMP(i) do { if (threadIdx.x == 0 && nhmc_pair_stamps) nhmc_pair_stamps[(long long)blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define NHMC_STAMP(i) do { } while (0)
+#endif
+
 // TOUT: as in k_sgemm -- the pair's result is stored transposed (and its epilogue runs in the transposed coordinates).
 template <int EPI, bool PRECLIP, int NW, bool TOUT = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
@@ -256,6 +265,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
   const int img = logical >> 2, q = logical & 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const float* __restrict__ Ximg = IN + (int64_t)img * D * D;
+  NHMC_STAMP(0);
+#ifdef NHMC_PAIR_STAMPS
+  if (threadIdx.x == 0 && nhmc_pair_stamps) nhmc_pair_stamps[(long long)blockIdx.x * 8 + 7] = wall_clock64();   // constant-rate, chip-wide
+#endif
 
 #pragma unroll
   for (int v = 0; v < D * SL / 4 / NT; ++v) {               // S1[:, slab] -> LDS, once
@@ -280,21 +293,38 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
 #pragma unroll
         for (int f = 0; f < F; ++f) fa[j][f] = ap[(int64_t)(2 * (c + j)) * D + 32 * f];
     };
+    // The LDS operand of k-pair j + LDS_AHEAD is read BEFORE the MFMAs of k-pair j are issued.  Written naively (read b, use
+    // b) the compiler emits ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 x v_mfma per k-pair, so a wave's matrix pipe idles for the
+    // LDS latency in front of every pair of MFMAs: phase stamps (tools/pair_stamps.hip, r3) showed a workgroup running
+    // alone at 39 % of the pipe rate in this loop and two co-resident ones at 62 %.
+    constexpr int LDS_AHEAD = 2;
     auto compute = [&](const float (&fa)[CHK][F], int c) {
+      float b0[CHK + LDS_AHEAD], b1[CHK + LDS_AHEAD];
+#pragma unroll
+      for (int j = 0; j < LDS_AHEAD; ++j) {
+        const int kk = 2 * (c + j);
+        b0[j] = s1s[(kk + lh) * SL + lr];
+        b1[j] = s1s[(kk + lh) * SL + 32 + lr];
+      }
 #pragma unroll
       for (int j = 0; j < CHK; ++j) {
-        const int kk = 2 * (c + j);
-        const float b0 = s1s[(kk + lh) * SL + lr], b1 = s1s[(kk + lh) * SL + 32 + lr];
+        if (j + LDS_AHEAD < CHK) {
+          const int kk = 2 * (c + j + LDS_AHEAD);
+          b0[j + LDS_AHEAD] = s1s[(kk + lh) * SL + lr];
+          b1[j + LDS_AHEAD] = s1s[(kk + lh) * SL + 32 + lr];
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // keep that read in front of this k-pair's MFMAs (the scheduler sinks it to its use otherwise)
 #pragma unroll
         for (int f = 0; f < F; ++f) {
           const float a = PRECLIP ? nhmc_clip1(fa[j][f]) : fa[j][f];
-          acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[f][0], 0, 0, 0);
-          acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[f][1], 0, 0, 0);
+          acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[j], acc[f][0], 0, 0, 0);
+          acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[j], acc[f][1], 0, 0, 0);
         }
       }
     };
     fetch(f0, 0);
     __syncthreads();                                        // S1 slab resident
+    NHMC_STAMP(1);
     for (int c0 = 0; c0 < D / 2; c0 += 2 * CHK) {
       fetch(f1, c0 + CHK);
       compute(f0, c0);
@@ -303,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
     }
   }
   // accumulators -> slab[k' = row of T1][r' = slab column]   (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 lh)
+  NHMC_STAMP(2);
   __syncthreads();                                          // every wave is done with the S1 slab the T1 slab overwrites
 #pragma unroll
   for (int f = 0; f < F; ++f)
@@ -324,20 +355,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
 #pragma unroll
         for (int f = 0; f < F; ++f) fb[j][f] = bp[(int64_t)(2 * (c + j)) * D + 32 * f];
     };
+    constexpr int LDS_AHEAD = 2;                            // as in phase 1: the T1 slab operand is read two k-pairs ahead
     auto compute = [&](const float (&fb)[CHK][F], int c) {
+      float a0[CHK + LDS_AHEAD], a1[CHK + LDS_AHEAD];
+#pragma unroll
+      for (int j = 0; j < LDS_AHEAD; ++j) {
+        const int kk = 2 * (c + j);
+        a0[j] = slab[(kk + lh) * SL + lr];
+        a1[j] = slab[(kk + lh) * SL + 32 + lr];
+      }
 #pragma unroll
       for (int j = 0; j < CHK; ++j) {
-        const int kk = 2 * (c + j);
-        const float a0 = slab[(kk + lh) * SL + lr], a1 = slab[(kk + lh) * SL + 32 + lr];
+        if (j + LDS_AHEAD < CHK) {
+          const int kk = 2 * (c + j + LDS_AHEAD);
+          a0[j + LDS_AHEAD] = slab[(kk + lh) * SL + lr];
+          a1[j + LDS_AHEAD] = slab[(kk + lh) * SL + 32 + lr];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, fb[j][f], acc[f][0], 0, 0, 0);
-          acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, fb[j][f], acc[f][1], 0, 0, 0);
+          acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb[j][f], acc[f][0], 0, 0, 0);
+          acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb[j][f], acc[f][1], 0, 0, 0);
         }
       }
     };
     fetch(f0, 0);
     __syncthreads();                                        // T1 slab complete
+    NHMC_STAMP(3);
     for (int c0 = 0; c0 < D / 2; c0 += 2 * CHK) {
       fetch(f1, c0 + CHK);
       compute(f0, c0);
@@ -347,6 +391,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
   }
 
   // ------------------------------------------------ epilogue: [64 rows][256 cols] through the slab's 64 KB -----------
+  NHMC_STAMP(4);
   __syncthreads();                                          // every wave is done reading the T1 slab
 #pragma unroll
   for (int f = 0; f < F; ++f)
@@ -358,6 +403,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
         slab[row * D + (TOUT ? (col ^ (row >> 2)) : col)] = acc[f][fa][r];       // 64 rows: row >> 2 < 16, stays in the 32-group
       }
   __syncthreads();
+  NHMC_STAMP(5);
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * D * D;
   const float* __restrict__ dm_img = (EPI == EPI_MULD || EPI == EPI_SRES) ? Dmap + (int64_t)c * D * D : nullptr;
@@ -423,8 +469,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
       }
       *reinterpret_cast<nhmc_v4f*>(&ge_img[off]) = ge;
     }
-    *reinterpret_cast<nhmc_v4f*>(&out_img[off]) = o;
+    __builtin_nontemporal_store(o, reinterpret_cast<nhmc_v4f*>(&out_img[off]));
   }
+  NHMC_STAMP(6);
   if (EPI == EPI_RESID || EPI == EPI_SRES) {
     __shared__ double red[NW];
     double sw = nhmc_wave_sum((double)lsum);
