@@ -101,7 +101,7 @@ def build_problem(device, B, chain_id0, seed=5678, deg='inpaint_random', model=N
     x_true = K.randn_philox(shape, seed, chain_id0, 2, device=device).clamp_(-1, 1)
     y = op.H(x_true) + (2 * sigma0) * torch.randn(B, op.M, device=device,
                                                   generator=torch.Generator(device=device).manual_seed(seed + chain_id0))
-    return dict(op=op, algo=algo, b=b, seq=seq, seq_next=seq_next, x=x, p=p, y=y, model=model, sigma0=sigma0)
+    return dict(op=op, algo=algo, b=b, seq=seq, seq_next=seq_next, x=x, p=p, y=y, model=model, sigma0=sigma0, deg=deg)
 
 
 def leapfrog_roofline(device, B, launches, n_elem=CH * DIM * DIM):
@@ -265,18 +265,31 @@ def data_term_roofline(device, prob, B, launches=30):
     e1.record()
     torch.cuda.synchronize()
     avg_s = e0.elapsed_time(e1) * 1e-3 / launches
+
+    def measured_traffic(key):
+        """HBM bytes per call from the committed PMC pass (profiles/traffic_ops.json), valid at the batch it was taken at."""
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_ops.json')
+        if not os.path.exists(tpath):
+            return {'traffic': None}
+        with open(tpath) as f:
+            rec = json.load(f)
+        if rec.get('chains_per_launch') != B or key not in rec:
+            return {'traffic': None}
+        return {'traffic': rec[key]['hbm_bytes_per_call'], 'traffic_source': rec.get('source')}
     if hasattr(op, 'factors'):
         proj = bool(getattr(op, 'projected', False))                   # 4 products (residual in the left singular basis) instead of 8
         flops = SPECTRAL_FLOP_PER_CHAIN * B // (2 if proj else 1)
         return dict(bound='mfma', achieved=round(flops / avg_s / 1e12, 1), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                    frac=round(flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), traffic=None, avg_us=round(avg_s * 1e6, 1),
+                    frac=round(flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), avg_us=round(avg_s * 1e6, 1),
+                    **measured_traffic('deblur_aniso_projected' if proj else 'deblur_aniso'),
                     kernel='spectral chain: data term + last-step VJP (%s), fp32 MFMA, %d products'
                            % ('nhmc_data_spectral_proj_vjp' if proj else 'nhmc_data_spectral_vjp', 4 if proj else 8),
                     flops_per_call=flops, dtype='f32')
     T = CH * DIM * DIM * 4
     alg = (4 * T + op.M * 4) * B
     return dict(bound='hbm', achieved=round(alg / avg_s / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4), traffic=None, avg_us=round(avg_s * 1e6, 1),
+                frac=round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 4), avg_us=round(avg_s * 1e6, 1),
+                **measured_traffic(prob.get('deg', '')),
                 kernel='data term fused with the last-step VJP (R xt, e; W g_xt, g_e; R y)', bytes_per_call=alg)
 
 
