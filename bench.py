@@ -455,26 +455,50 @@ def full_run_leg(device, prob, B, chunk, tau, trajectories):
     so the leg fits the bench's time budget; per score ladder the cost must equal the headline step's."""
     import types
     from nhmc import sampler
-    opt = types.SimpleNamespace(tau=tau, epsilon=EPS, m=1.0, sigma_0=2 * prob['sigma0'])
     x_orig = prob['x'].clamp(-1, 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = sampler.hmc_chains(prob['x'], prob['b'], prob['seq'], prob['seq_next'], prob['algo'], opt, prob['y'], prob['op'], x_orig,
-                             noise=sampler.PhiloxNoise(5678, 0), chunk=chunk, max_iters=trajectories)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    L, iters = res.L, res.iters
+    L = max(1, math.floor(tau / EPS))
+    # With random-init weights every proposal at the configured step size is rejected (dH >> 1), and a rejected trajectory
+    # skips the accept-side copies.  So half of the trajectories run at the configured (tau, eps) and half at 1/1000 of
+    # both (same L, dH ~ 0: accepted), each half its own hmc_chains run: both outcomes are inside the timed region.
+    legs = [(tau, EPS, trajectories - trajectories // 2), ((L + 0.5) * EPS * 1e-3, EPS * 1e-3, trajectories // 2)]
+    # one untimed one-step trajectory first (the W of this leg): the first hmc_chains of a process carries a one-time
+    # cost of ~6 s (measured: 23.7 s against 17.6 s for two otherwise identical runs; first-use allocations of its state,
+    # sample and cache buffers next to the bench's own), not a per-trajectory one
+    warm = types.SimpleNamespace(tau=1.5 * EPS, epsilon=EPS, m=1.0, sigma_0=2 * prob['sigma0'])
+    sampler.hmc_chains(prob['x'], prob['b'], prob['seq'], prob['seq_next'], prob['algo'], warm, prob['y'], prob['op'], x_orig,
+                       noise=sampler.PhiloxNoise(5678, 0), chunk=chunk, max_iters=1)
+    dt = ladders = 0.0
+    iters = accepted = rejected = 0
+    per_run = []
+    for tau_, eps_, n_traj in legs:
+        if n_traj <= 0:
+            continue
+        opt = types.SimpleNamespace(tau=tau_, epsilon=eps_, m=1.0, sigma_0=2 * prob['sigma0'])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = sampler.hmc_chains(prob['x'], prob['b'], prob['seq'], prob['seq_next'], prob['algo'], opt, prob['y'], prob['op'], x_orig,
+                                 noise=sampler.PhiloxNoise(5678, 0), chunk=chunk, max_iters=n_traj)
+        torch.cuda.synchronize()
+        per_run.append(round(time.perf_counter() - t0, 2))
+        dt += per_run[-1]
+        assert res.L == L, (res.L, L)
+        iters += res.iters
+        ladders += res.ladders
+        accepted += int(res.n_accept.sum())
+        rejected += int(res.n_reject.sum())
+    runs = sum(1 for leg in legs if leg[2] > 0)
     chunks = 1 if not chunk or chunk >= B else -(-B // chunk)
-    batch_ladders = res.ladders / chunks                               # batch-wide score ladders: iters * L + 1 (the start point)
+    batch_ladders = ladders / chunks                                   # batch-wide score ladders: iters * L + one per run (the start point)
     return dict(value=round(B * iters * L / dt, 3), unit='chain-steps/s', trajectories=iters, leapfrog_steps_per_trajectory=L,
-                tau=tau, chains=B, seconds=round(dt, 2), score_ladders=batch_ladders,
-                score_ladders_per_trajectory=round((batch_ladders - 1) / iters, 3),
+                tau=tau, chains=B, seconds=round(dt, 2), runs=runs, seconds_per_run=per_run, score_ladders=batch_ladders,
+                score_ladders_per_trajectory=round((batch_ladders - runs) / iters, 3),
                 score_ladders_without_the_gradient_cache=iters * (L + 1),
                 ms_per_ladder=round(1e3 * dt / batch_ladders, 2),
-                accepted=int(res.n_accept.sum()), rejected=int(res.n_reject.sum()),
+                accepted=accepted, rejected=rejected,
                 note='sampler.hmc_chains end to end (prime + trajectories, every kernel and the per-trajectory status read inside '
-                     'the timed region); value = chains x trajectories x L / seconds; ms_per_ladder (per batch-wide score ladder, '
-                     'the once-per-run start-point evaluation included) is comparable with ms_per_step')
+                     'the timed region; one untimed one-step trajectory before it), half of the trajectories at the configured step size (random-init weights: all rejected) and '
+                     'half at 1/1000 of it (all accepted), one run each; value = chains x trajectories x L / seconds; ms_per_ladder '
+                     '(per batch-wide score ladder, the once-per-run start-point evaluations included) is comparable with ms_per_step')
 
 
 def degradation_leg(device, deg, model, B, chunk, steps=2):
