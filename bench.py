@@ -554,11 +554,11 @@ def latent_problem(device, B, lo, chunk, seed=5678):
                 eps=eps, sig=sig, ws=ws)
 
 
-def latent_leg(device, steps=2):
+def latent_leg(device, steps=6):
     """configs[4] inside the default run: a few hmc_latent steps at 16 chains (`bench.py --latent` is the full line)."""
     from nhmc import sharding
     lp = latent_problem(device, B_LATENT, 0, None)
-    dt, _, _ = timed_steps(lp['eng'], lp['x'], lp['p'], lp['y'], lp['eps'], lp['sig'], lp['ws'], 1, steps, 1, 0, sharding, device)
+    dt, _, _ = timed_steps(lp['eng'], lp['x'], lp['p'], lp['y'], lp['eps'], lp['sig'], lp['ws'], 2, steps, 1, 0, sharding, device)   # W = 2: the first steps allocate
     return dict(value=round(B_LATENT * steps / dt, 3), unit='chain-steps/s', steps=steps, ms_per_step=round(1e3 * dt / steps, 2),
                 chains=B_LATENT, workload='BASELINE configs[4]: hmc_latent, [%d,64,64] latents, LDM U-Net + VQ-f4 decode in the loop, '
                                           'inpaint_random at 256x256, eps=0.1 sigma_y=0.5, random-init fp32' % lp['model'].channels)
