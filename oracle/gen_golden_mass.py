@@ -3,6 +3,7 @@
 
     python oracle/gen_golden_mass.py            # G11: the reference as it is (default, unstable torch.sort at :860)
     python oracle/gen_golden_mass.py stable     # G11b: g11b_hmc_mass_stable_16.npz
+    python oracle/gen_golden_mass.py stable 64  # G11c: g11c_hmc_mass_stable_64.npz (12 288 elements per rank transform)
 
 G11b pins the tie rule the product implements.  The rank transform sorts the per-element variance with torch's default
 sort (:860); among EQUAL variances (all of them are zero for the accepts of epochs 14..18, before the Welford
@@ -27,10 +28,9 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle.gen_golden import import_reference, np32, save, build_ops, tiny_model  # noqa: E402
 
 
-def main(stable=False):
+def main(stable=False, dim=16):
     ms = import_reference()
     from algos.unconditional import Unconditional
-    dim = 16
     ops, missing = build_ops(ms, dim, seed=1100)
     Hf = ops['inpaint']
     net = tiny_model()
@@ -92,7 +92,7 @@ def main(stable=False):
         assert rec['sorts'] > 0 and len(rec['tables']) == 2
         M = rec['tables']['M']
         assert bool((M[1:] > M[:-1]).all()), 'the mass table is not strictly increasing in the rank'
-        save('g11b_hmc_mass_stable_16.npz', x=np32(x), y_0=np32(y_0), x_orig=np32(x_orig), missing=np32(missing),
+        save('g11b_hmc_mass_stable_16.npz' if dim == 16 else f'g11c_hmc_mass_stable_{dim}.npz', x=np32(x), y_0=np32(y_0), x_orig=np32(x_orig), missing=np32(missing),
              seed=np.array(5678), sigma_0=np.array(sigma_0), tau=np.array(0.4), epsilon=np.array(0.05), out=np32(out),
              u=np.array(rec['u']), neg_dH=np.array(rec['neg_dH']), p0=np32(rec['p'][0]), p_last=np32(rec['p'][-1]),
              M_by_rank=np32(M), std_by_rank=np32(rec['tables']['std']), sorts=np.array(rec['sorts']),
@@ -101,6 +101,7 @@ def main(stable=False):
                            '(ties by index) and the float64 tiny score; nothing else the reference computes is changed'))
         print('iterations', len(rec['u']), 'returned', tuple(out.shape), 'rank transforms', rec['sorts'], 'tied elements', rec['ties'])
         return
+    assert dim == 16
     save('g11_hmc_mass_16.npz', x=np32(x), y_0=np32(y_0), x_orig=np32(x_orig), missing=np32(missing), seed=np.array(5678),
          sigma_0=np.array(sigma_0), tau=np.array(0.4), epsilon=np.array(0.05), out=np32(out), u=np.array(rec['u']),
          neg_dH=np.array(rec['neg_dH']))
@@ -108,4 +109,4 @@ def main(stable=False):
 
 
 if __name__ == '__main__':
-    main(stable=len(sys.argv) > 1 and sys.argv[1] == 'stable')
+    main(stable=len(sys.argv) > 1 and sys.argv[1] == 'stable', dim=int(sys.argv[2]) if len(sys.argv) > 2 else 16)

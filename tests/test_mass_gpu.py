@@ -71,7 +71,8 @@ def test_mass_from_variance_rank_transform():
             assert torch.equal(inv[c].reshape(-1).cpu(), inv_ref) and torch.equal(std[c].reshape(-1).cpu(), std_ref)
 
 
-def test_reference_diagonal_mass_run_on_the_gpu(golden, tiny_score):
+@pytest.mark.parametrize('fixture,dim', [('g11b_hmc_mass_stable_16.npz', 16), ('g11c_hmc_mass_stable_64.npz', 64)])
+def test_reference_diagonal_mass_run_on_the_gpu(golden, tiny_score, fixture, dim):
     """G11b = the reference's `hmc_test_conditioning` (main_sampling.py:776-894) run with ties of the rank transform broken
     by index (oracle/gen_golden_mass.py stable; the oracle reproduces it bit for bit, tests/test_mass_cpu.py), replayed on
     the GPU on the run's own tape: every accept decision outside the ambiguity band, the energy differences, and the 35
@@ -80,8 +81,8 @@ def test_reference_diagonal_mass_run_on_the_gpu(golden, tiny_score):
     from nhmc import operators, plugin, sampler
     from oracle.tiny_score import F64Score
     T = torch.from_numpy
-    g = golden('g11b_hmc_mass_stable_16.npz')
-    dim, dev = 16, torch.device('cuda')
+    g = golden(fixture)                                                  # G11c: the same reference run at 64 x 64
+    dev = torch.device('cuda')
     n = len(g['u'])
     torch.manual_seed(int(g['seed']))
     P, U = [], []
