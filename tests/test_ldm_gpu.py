@@ -333,3 +333,42 @@ def test_latent_cli_runs_the_reference_command_line(tmp_path, monkeypatch, capsy
         cli.main_latent(['--dataset', 'tiny', '--algo', 'hmc', '--deg', 'sr4', '--sigma_0', '0.05'])
     with pytest.raises(NotImplementedError):
         cli.main(['--dataset', 'tiny', '--algo', 'hmc_latent', '--deg', 'sr4', '--sigma_0', '0.05'])
+
+
+@pytest.mark.parametrize('deg', ['sr4', 'color', 'cs4', 'deblur_aniso'])
+def test_latent_trajectory_with_the_other_operators_on_the_decoded_image(golden, deg):
+    """`hmc_latent` applies H to the DECODED image (main_sampling_latent.py:683-684: loss = |y - H(decode(z))|^2), whatever
+    the degradation; the engine's latent branch takes the operator's data-term gradient on the image and pulls it back through
+    the decoder.  One trajectory on the G12 networks (float64 on both sides, as above) for operators other than inpainting,
+    against the latent oracle with the matching reference-order operator."""
+    from nhmc import operators, sampler
+    g = golden('g12_ldm_16.npz')
+    dev = torch.device('cuda')
+    base = small_model(g)
+    dim, B, L = 64, 2, 2
+    gen = torch.Generator().manual_seed(len(deg) * 131)
+    if deg == 'sr4':
+        ref_op, op = oops.BlockMeanRef(3, dim, 4), operators.SuperResolution(3, dim, 4, dev)
+    elif deg == 'color':
+        ref_op, op = oops.ColorRef(dim), operators.Colorization(dim, dev)
+    elif deg == 'cs4':
+        perm = torch.randperm(dim * dim, generator=gen)
+        ref_op, op = oops.WalshHadamardRef(3, dim, 4, perm), operators.WalshHadamardCS(3, dim, 4, perm, dev)
+    else:
+        k1, k2 = oops.gaussian_taps(20.0), oops.gaussian_taps(1.0)
+        ref_op = oops.SpectralBlurRef.from_kernels(k1 / k1.sum(), k2 / k2.sum(), 3, dim)
+        op = operators.Deblurring2D.from_factors(ref_op.U1, ref_op.U2, ref_op.V1, ref_op.V2, ref_op.D, dev)
+    x = torch.randn(B, 3, 16, 16, generator=gen)
+    p = torch.randn(B, 3, 16, 16, generator=gen)
+    y = ref_op.H(torch.rand(B, 3, dim, dim, generator=gen) * 2 - 1)
+    y = y + 0.1 * torch.randn(y.shape, generator=gen)
+    want = latent_ref.trajectory_latent(x, p.clone(), SEQ, SEQ_NEXT, ldm_ref.OracleLatent.from_product(base, f64=True), ref_op, y,
+                                        sigma_y=1.0, eps=0.05, m=1.0, L=L)
+    eng, _ = _engine(F64Product(base, dev), op, dev)
+    st = sampler.ChainState(B, 1.0, 0.05, dev)
+    st['eps_eff'].fill_(0.05)
+    st['sigma_y'].fill_(1.0)
+    got = sampler.run_trajectory(eng, x.to(dev), p.to(dev).clone(), y.to(dev), st, 1.0, L)
+    assert rel(got['x_prop'], want['x']) < 1e-4 and rel(got['p'], want['p']) < 1e-4
+    assert rel(got['xt'], want['xt']) < 1e-4 and rel(got['loss'], want['loss']) < 1e-4
+    assert float((got['H1'].cpu() - want['H1']).abs().max()) <= 1e-4 * float(want['H1'].abs().max())
