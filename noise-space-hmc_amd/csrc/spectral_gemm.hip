@@ -265,6 +265,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
   const int img = logical >> 2, q = logical & 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const float* __restrict__ Ximg = IN + (int64_t)img * D * D;
+#ifdef NHMC_PAIR_DELAY                                       // experiment (tools/pair_stamps.hip only): start the second resident workgroup of a CU late
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < NHMC_PAIR_DELAY; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   NHMC_STAMP(0);
 #ifdef NHMC_PAIR_STAMPS
   if (threadIdx.x == 0 && nhmc_pair_stamps) nhmc_pair_stamps[(long long)blockIdx.x * 8 + 7] = wall_clock64();   // constant-rate, chip-wide

@@ -13,8 +13,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 pairs = os.environ.get('NHMC_SPECTRAL_PAIRS', '1') != '0'
 
 
-def timeit(f, n=20):
-    for _ in range(3):
+def timeit(f, n=20, warm=3):          # NHMC_PAIR_BENCH_LONG=1: 300 warm-up calls, 200 timed (the chip at its loaded clock)
+    for _ in range(warm):
         f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,6 +44,10 @@ out['ge'] = ge.clone()
 ms_h = timeit(lambda: op.H(x), 10)
 ms_d = timeit(lambda: op.data_term(x, y, True), 10)
 ms_v = timeit(lambda: op.fused_last_vjp(x, e6, at, an, y, g_e_out=ge, xt_next=cur), 10)
+if os.environ.get('NHMC_PAIR_BENCH_LONG'):                            # the same after 300 warm-up calls, 200 timed: the chip at its loaded clock
+    ms_h = timeit(lambda: op.H(x), 200, 300)
+    ms_d = timeit(lambda: op.data_term(x, y, True), 200, 300)
+    ms_v = timeit(lambda: op.fused_last_vjp(x, e6, at, an, y, g_e_out=ge, xt_next=cur), 200, 300)
 print(f'pairs={int(pairs)} B={B}: H {ms_h*1e3:.1f} us ({fl/2/ms_h/1e9:.1f} TFLOP/s)  data term {ms_d*1e3:.1f} us ({fl/ms_d/1e9:.1f} TFLOP/s)  '
       f'data term + last VJP {ms_v*1e3:.1f} us ({fl/ms_v/1e9:.1f} TFLOP/s)')
 path = '/tmp/nhmc_pair_ab.pt'          # hundreds of MB: keep it out of gpurun_out

@@ -39,6 +39,37 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(nhmc_pair_stamps), &ST, sizeof(long long*)));
   if (pair256<EPI_MULD, false>(IN, S1, S2, OUT, DM, nullptr, nullptr, n_img, C, nullptr)) { std::printf("launch failed\n"); return 1; }
   CK(hipDeviceSynchronize());
+  {                                                                  // the unstamped kernel's duration, by events
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(nhmc_pair_stamps), &null_ptr, sizeof(long long*)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, nullptr));
+    for (int it = 0; it < 50; ++it)
+      if (pair256<EPI_MULD, false>(IN, S1, S2, OUT, DM, nullptr, nullptr, n_img, C, nullptr)) { std::printf("launch failed\n"); return 1; }
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("50 back-to-back launches on the same buffers: %.1f us each\n", ms * 1000.f / 50);
+    // the same over 8 input / output pairs (8 x 2 x 50 MB at 64 chains: more than the 256 MB memory-side cache holds), and
+    // chained (each launch reads what the previous one wrote), as the product's four launches are
+    constexpr int R = 8;
+    float* buf[R + 1];
+    for (int r = 0; r <= R; ++r) { CK(hipMalloc(&buf[r], img * 4)); CK(hipMemcpy(buf[r], IN, img * 4, hipMemcpyDeviceToDevice)); }
+    for (int mode = 0; mode < 2; ++mode) {
+      CK(hipEventRecord(e0, nullptr));
+      for (int it = 0; it < 48; ++it) {
+        const float* src = mode == 0 ? buf[it % R] : buf[it % (R + 1)];
+        float* dst = mode == 0 ? buf[(it + R / 2) % R] : buf[(it + 1) % (R + 1)];
+        if (pair256<EPI_MULD, false>(src, S1, S2, dst, DM, nullptr, nullptr, n_img, C, nullptr)) { std::printf("launch failed\n"); return 1; }
+      }
+      CK(hipEventRecord(e1, nullptr));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      std::printf("48 launches rotating over %d buffers%s: %.1f us each\n", mode == 0 ? R : R + 1,
+                  mode == 0 ? "" : ", each reading the previous one's output", ms * 1000.f / 48);
+    }
+  }
   std::vector<long long> st((size_t)n_wg * 8);
   CK(hipMemcpy(st.data(), ST, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
   // start times on the constant-rate wall clock (100 MHz, chip-wide); phase lengths on the shader clock of the workgroup's own CU
