@@ -244,12 +244,21 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 __device__ long long* nhmc_pair_stamps = nullptr;               // [workgroup][8]
 #define NHMC_STAMP(i) do { if (threadIdx.x == 0 && nhmc_pair_stamps) nhmc_pair_stamps[(long long)blockIdx.x * 8 + (i)] = clock64(); } while (0)
 #else
-#define NHMC_STAMP(i) do { } while (0)
+// Without the stamps every phase boundary still gets a basic-block split: a branch on a condition the compiler cannot
+// evaluate (channels is never INT_MAX: n_chains * channels <= 65535 is checked on the host) around a store it cannot
+// drop.  The machine scheduler works per basic block; with the whole kernel in one block it hoists the next phase's global
+// loads over the phase boundaries and allocates 156-179 VGPRs (25-48 spilled once the launch bounds ask for 128); split
+// where the stamps split it, the same code takes 103-124 and two blocks are resident per CU.  One scalar compare per boundary.
+#define NHMC_STAMP(i) do { if (channels == 0x7fffffff) OUT[0] = (float)clock64(); } while (0)
 #endif
 
 // TOUT: as in k_sgemm -- the pair's result is stored transposed (and its epilogue runs in the transposed coordinates).
 template <int EPI, bool PRECLIP, int NW, bool TOUT = false>
-__global__ __launch_bounds__(64 * NW, 2) void k_pair256(
+// __launch_bounds__' second argument is waves per SIMD (not blocks per CU): two resident blocks of NW waves on 4 SIMDs are
+// NW / 2 waves per SIMD, i.e. at most 128 VGPRs for NW = 8.  Written as "2" (rounds 2 and 3 until the phase-stamp harness,
+// whose stamps happened to hold the allocation at 104, ran 13 % faster than the product build of the same source) the
+// compiler took 156-179 registers and ONE block fitted a CU.
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_pair256(
     const float* __restrict__ IN, const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int channels, VjpArgs vj) {
   constexpr int D = 256, SL = 64, NT = 64 * NW, CHK = 16;   // CHK: k-pairs fetched ahead per register set
@@ -406,8 +415,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
         const int row = fa * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = (wave * F + f) * 32 + lr;
         slab[row * D + (TOUT ? (col ^ (row >> 2)) : col)] = acc[f][fa][r];       // 64 rows: row >> 2 < 16, stays in the 32-group
       }
-  __syncthreads();
-  NHMC_STAMP(5);
   const int c = img % channels;
   float* __restrict__ out_img = OUT + (int64_t)img * D * D;
   const float* __restrict__ dm_img = (EPI == EPI_MULD || EPI == EPI_SRES) ? Dmap + (int64_t)c * D * D : nullptr;
@@ -423,43 +430,64 @@ __global__ __launch_bounds__(64 * NW, 2) void k_pair256(
     const float a = vj.at[chain], an = vj.at_next[chain];
     c1 = sqrtf(1.0f - a); c2 = sqrtf(a); c3 = sqrtf(an); c4 = sqrtf(1.0f - an);
   }
-  float lsum = 0.0f;
-#pragma unroll 4
-  for (int v = 0; v < SL * D / 4 / NT; ++v) {
+  // the epilogue's global operands (multiplier map / observation / clip-mask source / the VJP's xt and e) are requested HERE,
+  // before the barrier that ends the staging: the accumulators and the operand ring are dead, so their registers hold the
+  // 8 (16 for the VJP) float4 per thread, and the loads' latency runs under the barrier instead of inside the store loop
+  constexpr int NV = SL * D / 4 / NT;
+  constexpr bool USE_DM = EPI == EPI_MULD || EPI == EPI_SRES;
+  constexpr bool USE_AUX = EPI == EPI_RESID || EPI == EPI_SRES || EPI == EPI_GRAD || EPI == EPI_VJP;
+  auto offset_of = [&](int v) {
     const int idx = tid + v * NT;
-    int off;
+    if (TOUT) { const int r4 = idx % (SL / 4), col = idx / (SL / 4); return col * D + q * SL + r4 * 4; }
+    const int row = idx / (D / 4), c4i = idx % (D / 4);
+    return (q * SL + row) * D + c4i * 4;
+  };
+  nhmc_v4f pre_dm[USE_DM ? NV : 1], pre_aux[USE_AUX ? NV : 1], pre_e[EPI == EPI_VJP ? NV : 1];
+  const bool have_aux = USE_AUX && aux_img != nullptr;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int off = offset_of(v);
+    if (USE_DM) pre_dm[v] = *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
+    if (USE_AUX) { if (have_aux) pre_aux[v] = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]); }
+    if (EPI == EPI_VJP) pre_e[v] = *reinterpret_cast<const nhmc_v4f*>(&e_img[off]);
+  }
+  __syncthreads();
+  NHMC_STAMP(5);
+  float lsum = 0.0f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int idx = tid + v * NT;
+    const int off = offset_of(v);
     nhmc_v4f o;
     if (TOUT) {                                             // 4 consecutive rows of one column = 4 consecutive floats of OUT_T
       const int r4 = idx % (SL / 4), col = idx / (SL / 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = slab[(r4 * 4 + j) * D + (col ^ r4)];
-      off = col * D + q * SL + r4 * 4;
     } else {
       const int row = idx / (D / 4), c4i = idx % (D / 4);
-      off = (q * SL + row) * D + c4i * 4;
       o = *reinterpret_cast<const nhmc_v4f*>(&slab[row * D + c4i * 4]);
     }
-    if (EPI == EPI_MULD) o = o * *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
+    if (EPI == EPI_MULD) o = o * pre_dm[v];
     if (EPI == EPI_RESID) {
-      o = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]) - o;                   // r = y - H x
+      o = pre_aux[v] - o;                                   // r = y - H x
       lsum += o.x * o.x; lsum += o.y * o.y; lsum += o.z * o.z; lsum += o.w * o.w;
     }
     if (EPI == EPI_SRES) {
-      const nhmc_v4f d = *reinterpret_cast<const nhmc_v4f*>(&dm_img[off]);
-      o = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]) - o * d;             // r^ = U1^T (y - H x) U2
+      const nhmc_v4f d = pre_dm[v];
+      o = pre_aux[v] - o * d;                               // r^ = U1^T (y - H x) U2
       lsum += o.x * o.x; lsum += o.y * o.y; lsum += o.z * o.z; lsum += o.w * o.w;
       o = o * d;
     }
     if (EPI == EPI_GRAD) {
       o = -(2.0f * o);
-      if (aux_img) {
-        const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
+      if (have_aux) {
+        const nhmc_v4f xv = pre_aux[v];
         o.x = o.x * nhmc_in1(xv.x); o.y = o.y * nhmc_in1(xv.y); o.z = o.z * nhmc_in1(xv.z); o.w = o.w * nhmc_in1(xv.w);
       }
     }
     if (EPI == EPI_VJP) {                                   // same op order as k_mix_bwd<false,false>, final_clip = 1
-      const nhmc_v4f xv = *reinterpret_cast<const nhmc_v4f*>(&aux_img[off]);
-      const nhmc_v4f ev = *reinterpret_cast<const nhmc_v4f*>(&e_img[off]);
+      const nhmc_v4f xv = pre_aux[v];
+      const nhmc_v4f ev = pre_e[v];
       nhmc_v4f ge;
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
