@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * NW * NW, (NW == 2 && EPI != EPI_NONE) ? 4 : 1)
 // and epilogue overlap the other's MFMAs), 8 waves per block.
 // The main loops have NO block barrier: the operand every wave shares is resident in LDS for the whole phase (the S1
 // slab in phase 1, staged once; the T1 slab in phase 2), and the operand a wave needs alone (its 32 rows of IN, its 32
-// columns of S2) is read straight from global / L2 into MFMA fragments, 16 k-pairs ahead in registers, so waves drift
+// columns of S2) is read straight from global / L2 into MFMA fragments, NHMC_PAIR_CHK (8) k-pairs ahead in registers, two sets, so waves drift
 // freely and the two waves of a SIMD fill each other's latencies.  MFMA count, k order and epilogues are those of the
 // two-launch form: the same bits.  Measured at B = 64 (data term + last VJP, tools/pair_bench.py): one product per
 // launch 525 us; this form 522 us (98.7 TFLOP/s); with per-K-step LDS staging of both operands + a block barrier 562 us
@@ -252,6 +252,12 @@ __device__ long long* nhmc_pair_stamps = nullptr;               // [workgroup][8
 #define NHMC_STAMP(i) do { if (channels == 0x7fffffff) OUT[0] = (float)clock64(); } while (0)
 #endif
 
+#ifndef NHMC_LDS_AHEAD
+#define NHMC_LDS_AHEAD 2      // k-pairs by which the LDS operand read leads its MFMAs
+#endif
+#ifndef NHMC_PAIR_CHK
+#define NHMC_PAIR_CHK 8       // k-pairs per register set of the global operand ring (measured with two blocks resident: 4 / 8 / 16 / 32 -> 458.9 / 458.8 / 465.0 / 478.3 us per data term + last VJP)
+#endif
 // TOUT: as in k_sgemm -- the pair's result is stored transposed (and its epilogue runs in the transposed coordinates).
 template <int EPI, bool PRECLIP, int NW, bool TOUT = false>
 // __launch_bounds__' second argument is waves per SIMD (not blocks per CU): two resident blocks of NW waves on 4 SIMDs are
@@ -261,7 +267,7 @@ template <int EPI, bool PRECLIP, int NW, bool TOUT = false>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_pair256(
     const float* __restrict__ IN, const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ OUT,
     const float* __restrict__ Dmap, const float* __restrict__ aux, double* __restrict__ ws, int channels, VjpArgs vj) {
-  constexpr int D = 256, SL = 64, NT = 64 * NW, CHK = 16;   // CHK: k-pairs fetched ahead per register set
+  constexpr int D = 256, SL = 64, NT = 64 * NW, CHK = NHMC_PAIR_CHK;   // CHK: k-pairs fetched ahead per register set
   constexpr int F = 8 / NW;                                  // 32-wide fragments of the wave's private operand (NW = 4: 2 x 2 MFMA tiles)
   extern __shared__ float lds[];
   // ONE 64 KB region, three lives: S1[:, slab] during phase 1, T1[:, slab] during phase 2 (it lives in the accumulators
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_pair256(
     // b) the compiler emits ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 x v_mfma per k-pair, so a wave's matrix pipe idles for the
     // LDS latency in front of every pair of MFMAs: phase stamps (tools/pair_stamps.hip, r3) showed a workgroup running
     // alone at 39 % of the pipe rate in this loop and two co-resident ones at 62 %.
-    constexpr int LDS_AHEAD = 2;
+    constexpr int LDS_AHEAD = NHMC_LDS_AHEAD;
     auto compute = [&](const float (&fa)[CHK][F], int c) {
       float b0[CHK + LDS_AHEAD], b1[CHK + LDS_AHEAD];
 #pragma unroll
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_pair256(
 #pragma unroll
         for (int f = 0; f < F; ++f) fb[j][f] = bp[(int64_t)(2 * (c + j)) * D + 32 * f];
     };
-    constexpr int LDS_AHEAD = 2;                            // as in phase 1: the T1 slab operand is read two k-pairs ahead
+    constexpr int LDS_AHEAD = NHMC_LDS_AHEAD;                            // as in phase 1: the T1 slab operand is read two k-pairs ahead
     auto compute = [&](const float (&fb)[CHK][F], int c) {
       float a0[CHK + LDS_AHEAD], a1[CHK + LDS_AHEAD];
 #pragma unroll
